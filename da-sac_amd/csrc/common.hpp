@@ -1,0 +1,64 @@
+// Shared plumbing for libdasac_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "dasac_hip.h"
+
+namespace dasac {
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kNumXcd = 8;         // MI355X: 8 XCDs x 32 CUs
+constexpr int kNumCu = 256;
+
+int fail(int code, const char* fmt, ...);   // records dasac_last_error(), returns code
+
+inline hipStream_t as_stream(dasac_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define DASAC_REQUIRE(cond, ...)                                        \
+  do {                                                                  \
+    if (!(cond)) return ::dasac::fail(DASAC_EINVAL, __VA_ARGS__);       \
+  } while (0)
+
+#define DASAC_CHECK_LAUNCH(what)                                                          \
+  do {                                                                                    \
+    hipError_t e_ = hipGetLastError();                                                    \
+    if (e_ != hipSuccess) return ::dasac::fail(DASAC_ELAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+#define DASAC_HIP(call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) return ::dasac::fail(DASAC_ELAUNCH, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs several times over
+inline int stream_grid(int64_t work_items, int block, int max_blocks = kNumCu * 16) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return static_cast<int>(g);
+}
+
+// ---- wave / block reductions (64-wide) ------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace dasac

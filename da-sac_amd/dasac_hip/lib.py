@@ -1,0 +1,73 @@
+"""ctypes loader for libdasac_hip.so.  PyTorch is only the allocator / stream provider: every
+call hands raw `data_ptr()`s, sizes and the current HIP stream to the C ABI of include/dasac_hip.h."""
+import ctypes as C
+import os
+
+import torch
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdasac_hip.so")
+
+_p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/dasac_hip.h
+PROTOTYPES = {
+    "dasac_version": (_i, []),
+    "dasac_last_error": (C.c_char_p, []),
+    "dasac_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    "dasac_pseudo_labels_workspace": (_sz, [_i, _i, _l]),
+    "dasac_pseudo_labels": (_i, [_p, _p, _p, _f, _f, _i, _i, _l, _p, _p, _p, _p, _sz, _p]),
+}
+
+
+class DasacError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises if it was not built (run `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise DasacError("libdasac_hip.so not found at {} -- build it with `python -c 'import __graft_entry__ as g; "
+                             "g.build()'`; there is no CPU fallback".format(LIB_PATH))
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise DasacError("{} failed ({}): {}".format(what, code, load().dasac_last_error().decode()))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DasacError("dasac_hip ops run on the MI355X only (got a {} tensor); no CPU fallback".format(t.device))
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Per-(device, stream) grow-only scratch buffer (the C ABI never allocates)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
