@@ -1,0 +1,548 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every nn.Conv2d call of the reference backbone (models/deeplabv2.py:59,65-66,70,107,
+// 122,147-148,262-263; models/fcn.py:49,53,57,78,88) -- 1x1, dilated 3x3, 7x7/2 stem, and the
+// four-branch ASPP sum as ONE contraction -- for forward, data-gradient and weight-gradient.
+//
+//   forward / dgrad :  Out[m][pix] = sum_k  Wp[k][m] * gather(X, k, pix)        (conv_gemm)
+//   wgrad           :  G[m][k]     = sum_pix dZ[m][pix] * gather(X, k, pix)     (conv_wgrad)
+//
+// `gather` is table driven: row k of the im2col matrix is (channel plane offset, dh, dw), so one
+// kernel covers any kernel size / dilation / padding / multi-branch layout; the table row is
+// wave-uniform (scalar loads), lanes run along pixels (coalesced NCHW reads).  Tiles go through
+// LDS ([k][m] / [k][pix], conflict-free ds_read_b32 in the MFMA operand pattern), register-staged
+// double buffering: the global loads of K-step t+1 are in flight while the 32..64 MFMAs of step t
+// issue.  The BN(eval) scale/shift, bias, residual add, ReLU and the ReLU-mask of the backward
+// pass are folded into the epilogue ("ABN": conv+BN+ReLU in one pass, no extra HBM round trip).
+//
+// Roofline: MFMA-bound, 2*M*Npix*K flops per launch against the 157.3 TFLOP/s fp32 matrix peak.
+#include "common.hpp"
+
+namespace dasac {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 16;            // K-step of the forward/dgrad kernel
+constexpr int kThreads = 256;      // 4 waves
+constexpr int kInvalid = 1 << 20;  // dh of a padded table row: never in bounds
+
+struct GemmGeom {
+  // gathered tensor X [Nb, Cx, H, W]
+  int H, W, CxHW;                // CxHW = Cx*H*W (image stride)
+  // pixel grid of the GEMM's N dimension: Nb x OH x OW, gather coordinate = o*stride + d
+  int OH, OW, stride;
+  int Npix;                      // Nb*OH*OW
+  int M, Mpad, Kpad;
+  // output tensor [Nb, M, OutH, OutW]; element (oh*ostride, ow*ostride)
+  int OutH, OutW, ostride;
+};
+
+struct Epilogue {
+  const float* scale;   // [M] or null
+  const float* shift;   // [M] or null
+  const float* res;     // same layout as out, or null  (added before ReLU)
+  const float* mask;    // same layout as out, or null  (out = mask>0 ? out : 0, ReLU backward)
+  int relu;
+};
+
+// ------------------------------------------------------------------------------------------
+// forward / dgrad kernel
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M>
+__global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                      const int4* __restrict__ tab, float* __restrict__ Out,
+                                                      GemmGeom g, Epilogue ep, int m_tiles, int n_tiles) {
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_VEC = kBK * BM / 4;                    // float4 loads for the weight tile
+  constexpr int A_PER_T = (A_VEC + kThreads - 1) / kThreads;
+  constexpr int B_ROWS_PASS = kThreads / BN > 0 ? kThreads / BN : 1;   // k rows covered per pass
+  constexpr int B_COLS_T = BN / kThreads > 0 ? BN / kThreads : 1;      // pixel columns per thread
+  constexpr int B_LOADS = kBK / B_ROWS_PASS;
+  static_assert(TM >= 1 && TN >= 1, "tile too small");
+
+  __shared__ float sA[2][kBK * BM];
+  __shared__ float sB[2][kBK * BN];
+
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole pixel tiles so that the M
+  // tiles sharing an activation tile hit the same L2.
+  int bid = blockIdx.x;
+  const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
+  const int n_tile = (slot / m_tiles) * kNumXcd + xcd;
+  const int m_tile = slot % m_tiles;
+  if (n_tile >= n_tiles) return;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- per-thread pixel columns of the gather ------------------------------------------
+  const int OHW = g.OH * g.OW;
+  int pixbase[B_COLS_T], ih0[B_COLS_T], iw0[B_COLS_T];
+  const int bcol0 = (BN >= kThreads) ? t : (t % BN);
+  const int brow0 = (BN >= kThreads) ? 0 : __builtin_amdgcn_readfirstlane(t / BN);
+#pragma unroll
+  for (int c = 0; c < B_COLS_T; ++c) {
+    const int pix = n0 + bcol0 + c * kThreads;
+    if (pix < g.Npix) {
+      const int n = pix / OHW, r = pix - n * OHW;
+      const int oh = r / g.OW, ow = r - oh * g.OW;
+      ih0[c] = oh * g.stride;
+      iw0[c] = ow * g.stride;
+      pixbase[c] = n * g.CxHW + ih0[c] * g.W + iw0[c];
+    } else {
+      ih0[c] = -kInvalid;
+      iw0[c] = 0;
+      pixbase[c] = 0;
+    }
+  }
+
+  float4 ra[A_PER_T];
+  float rb[B_LOADS * B_COLS_T];
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * kBK;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int v = t + i * kThreads;
+      if (A_VEC % kThreads == 0 || v < A_VEC) {
+        const int row = v / (BM / 4), c4 = v % (BM / 4);
+        ra[i] = *reinterpret_cast<const float4*>(Wp + (size_t)(k0 + row) * g.Mpad + m0 + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < B_LOADS; ++r) {
+      const int4 e = tab[k0 + brow0 + r * B_ROWS_PASS];   // wave-uniform -> scalar load
+#pragma unroll
+      for (int c = 0; c < B_COLS_T; ++c) {
+        const int ih = ih0[c] + e.y, iw = iw0[c] + e.z;
+        const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        rb[r * B_COLS_T + c] = ok ? X[pixbase[c] + e.x] : 0.f;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int v = t + i * kThreads;
+      if (A_VEC % kThreads == 0 || v < A_VEC) *reinterpret_cast<float4*>(&sA[buf][v * 4]) = ra[i];
+    }
+#pragma unroll
+    for (int r = 0; r < B_LOADS; ++r)
+#pragma unroll
+      for (int c = 0; c < B_COLS_T; ++c)
+        sB[buf][(brow0 + r * B_ROWS_PASS) * BN + bcol0 + c * kThreads] = rb[r * B_COLS_T + c];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = g.Kpad / kBK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const float* a_base = &sA[buf][wm * WM + li];
+    const float* b_base = &sB[buf][wn * WN + li];
+#pragma unroll
+    for (int kk = 0; kk < kBK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = a_base[(2 * kk + lh) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = b_base[(2 * kk + lh) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: BN(eval) scale/shift | bias, residual, ReLU, ReLU-backward mask -----------
+  const int OutHW = g.OutH * g.OutW;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pix = n0 + wn * WN + j * 32 + li;
+    if (pix >= g.Npix) continue;
+    const int n = pix / OHW, r = pix - n * OHW;
+    const int oh = r / g.OW, ow = r - oh * g.OW;
+    const int obase = n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int m = m0 + wm * WM + i * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float v = acc[i][j][rg];
+        if (ep.scale) v = v * ep.scale[m];
+        if (ep.shift) v = v + ep.shift[m];
+        const int idx = obase + m * OutHW;
+        if (ep.res) v = v + ep.res[idx];
+        if (ep.relu) v = fmaxf(v, 0.f);
+        if (ep.mask) v = ep.mask[idx] > 0.f ? v : 0.f;
+        Out[idx] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight-gradient kernel: reduction over pixels, split across blockIdx.z-like chunks
+//   P[split][m][k] = sum_{pix in chunk} dZ[m][pix] * gather(X,k,pix)
+// LDS tiles keep the natural [row][pix] order with an odd row pitch (33) so that both the
+// coalesced tile writes and the strided MFMA operand reads are bank-conflict free.
+// ------------------------------------------------------------------------------------------
+constexpr int kWgPix = 32;   // pixels per K-step
+constexpr int kWgPitch = 33;
+
+template <int BM, int BN, int WAVES_M>
+__global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
+                                                       const int4* __restrict__ tab, float* __restrict__ P,
+                                                       GemmGeom g, int m_tiles, int k_tiles, int pix_per_split) {
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_LOADS = BM / 8, B_LOADS = BN / 8;      // 8 rows of 32 pixels per pass of 256 threads
+
+  __shared__ float sA[2][BM * kWgPitch];
+  __shared__ float sB[2][BN * kWgPitch];
+
+  const int tile = blockIdx.x % (m_tiles * k_tiles), split = blockIdx.x / (m_tiles * k_tiles);
+  const int m_tile = tile % m_tiles, k_tile = tile / m_tiles;
+  const int m0 = m_tile * BM, kb0 = k_tile * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+  const int pl = t & 31, prow = t >> 5;                  // loader: pixel lane, row within pass
+
+  const int OHW = g.OH * g.OW;
+  const int p_begin = split * pix_per_split;
+  const int p_end = min(p_begin + pix_per_split, g.Npix);
+  const int steps = (p_end - p_begin + kWgPix - 1) / kWgPix;
+
+  // table rows of this thread's B loads are fixed for the whole kernel
+  int4 te[B_LOADS];
+#pragma unroll
+  for (int r = 0; r < B_LOADS; ++r) te[r] = tab[kb0 + prow + r * 8];
+
+  float ra[A_LOADS], rb[B_LOADS];
+  const int zimg = g.M * OHW;                            // dZ image stride
+
+  auto load_tile = [&](int s) {
+    const int pix = p_begin + s * kWgPix + pl;
+    const bool pv = pix < p_end;
+    int n = 0, r = 0, oh = 0, ow = 0;
+    if (pv) {
+      n = pix / OHW;
+      r = pix - n * OHW;
+      oh = r / g.OW;
+      ow = r - oh * g.OW;
+    }
+    const int zbase = n * zimg + r;
+    const int ih0 = oh * g.stride, iw0 = ow * g.stride;
+    const int xbase = n * g.CxHW + ih0 * g.W + iw0;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int m = m0 + prow + i * 8;
+      ra[i] = (pv && m < g.M) ? dZ[zbase + m * OHW] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int ih = ih0 + te[i].y, iw = iw0 + te[i].z;
+      const bool ok = pv && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      rb[i] = ok ? X[xbase + te[i].x] : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) sA[buf][(prow + i * 8) * kWgPitch + pl] = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) sB[buf][(prow + i * 8) * kWgPitch + pl] = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (steps > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < steps) load_tile(s + 1);
+    const float* a_base = &sA[buf][(wm * WM + li) * kWgPitch + lh];
+    const float* b_base = &sB[buf][(wn * WN + li) * kWgPitch + lh];
+#pragma unroll
+    for (int kk = 0; kk < kWgPix / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = a_base[i * 32 * kWgPitch + 2 * kk];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = b_base[j * 32 * kWgPitch + 2 * kk];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < steps) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial slab [split][Mpad][Kpad], k contiguous
+  float* slab = P + (size_t)split * g.Mpad * g.Kpad;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int k = kb0 + wn * WN + j * 32 + li;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int m = m0 + wm * WM + i * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
+        slab[(size_t)m * g.Kpad + k] = acc[i][j][rg];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// small helpers: gather table, weight packing, wgrad slab reduction
+// ------------------------------------------------------------------------------------------
+struct TapGroups {
+  int n;             // number of branches (1, or 4 for the fused ASPP)
+  int kh[4], kw[4], dil[4], pad[4];
+};
+
+// table row k = tap*C + c  (tap-major), tap enumerates (branch, kh, kw)
+__global__ void build_table(int4* tab, TapGroups tg, int C, int K, int Kpad, int planeHW, int W, int sign) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Kpad) return;
+  int4 e = make_int4(0, kInvalid, kInvalid, 0);
+  if (k < K) {
+    int tap = k / C;
+    const int c = k - tap * C;
+    int b = 0;
+    while (b < tg.n - 1 && tap >= tg.kh[b] * tg.kw[b]) {
+      tap -= tg.kh[b] * tg.kw[b];
+      ++b;
+    }
+    const int kh = tap / tg.kw[b], kw = tap - kh * tg.kw[b];
+    const int dh = sign * (kh * tg.dil[b] - tg.pad[b]), dw = sign * (kw * tg.dil[b] - tg.pad[b]);
+    e = make_int4(c * planeHW + dh * W + dw, dh, dw, 0);
+  }
+  tab[k] = e;
+}
+
+// mode 0 (forward):  Wp[(tap0+tap)*Cin + ci][co] = W[co][ci][tap]
+// mode 1 (dgrad):    Wp[(tap0+tap)*Cout + co][ci] = W[co][ci][tap] * (scale ? scale[co] : 1)
+__global__ void pack_weights(const float* __restrict__ Wt, const float* __restrict__ scale, float* __restrict__ Wp,
+                             int Cout, int Cin, int taps, int tap0, int Mpad, int mode) {
+  const int rows = taps * (mode == 0 ? Cin : Cout);
+  const int64_t total = (int64_t)rows * Mpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / Mpad), m = (int)(i - (int64_t)row * Mpad);
+    const int C = mode == 0 ? Cin : Cout;
+    const int tap = row / C, c = row - tap * C;
+    float v = 0.f;
+    if (mode == 0) {
+      if (m < Cout) v = Wt[((int64_t)m * Cin + c) * taps + tap];
+    } else {
+      if (m < Cin) {
+        v = Wt[((int64_t)c * Cin + m) * taps + tap];
+        if (scale) v = v * scale[c];
+      }
+    }
+    Wp[(int64_t)(tap0 * C + row) * Mpad + m] = v;
+  }
+}
+
+// dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G)
+// one block per output channel.
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P, int splits, int Mpad, int Kpad,
+                                                    const float* __restrict__ Wt, const float* __restrict__ scale,
+                                                    float* __restrict__ dW, float* __restrict__ dot, int Cin, int taps,
+                                                    int tap0) {
+  const int co = blockIdx.x;
+  const int n = Cin * taps;
+  const float sc = scale ? scale[co] : 1.f;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    // i runs in the packed order (tap-major) so the slab reads coalesce
+    const int tap = i / Cin, ci = i - tap * Cin;
+    const size_t kidx = (size_t)co * Kpad + (size_t)(tap0 + tap) * Cin + ci;
+    float gsum = 0.f;
+    for (int s = 0; s < splits; ++s) gsum += P[(size_t)s * Mpad * Kpad + kidx];
+    const size_t widx = ((size_t)co * Cin + ci) * taps + tap;
+    if (dot) part += gsum * Wt[widx];
+    dW[widx] = gsum * sc;
+  }
+  if (dot) {
+    __shared__ float red[4];
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) dot[co] += red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int Mpad, int Kpad,
+                     int OutH, int OutW, int ostride) {
+  DASAC_REQUIRE(Nb > 0 && Cx > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && stride > 0 && M > 0, "conv: bad geometry");
+  DASAC_REQUIRE((int64_t)Nb * Cx * H * W < (1ll << 31) && (int64_t)Nb * M * OutH * OutW < (1ll << 31) &&
+                    (int64_t)Nb * OH * OW < (1ll << 31),
+                "conv: tensor exceeds 2^31 elements");
+  DASAC_REQUIRE(Kpad % kBK == 0 && Mpad % 32 == 0 && Mpad >= M, "conv: bad padding Kpad=%d Mpad=%d", Kpad, Mpad);
+  g.H = H; g.W = W; g.CxHW = Cx * H * W; g.OH = OH; g.OW = OW; g.stride = stride; g.Npix = Nb * OH * OW;
+  g.M = M; g.Mpad = Mpad; g.Kpad = Kpad; g.OutH = OutH; g.OutW = OutW; g.ostride = ostride;
+  return DASAC_OK;
+}
+
+template <int BM, int BN, int WAVES_M>
+static void launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
+                        const Epilogue& ep, hipStream_t s) {
+  const int m_tiles = (g.M + BM - 1) / BM;
+  const int n_tiles = (g.Npix + BN - 1) / BN;
+  const int n_tiles_pad = (n_tiles + kNumXcd - 1) / kNumXcd * kNumXcd;
+  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
+                     ep, m_tiles, n_tiles);
+}
+
+template <int BM, int BN, int WAVES_M>
+static void launch_wgrad(const float* dZ, const float* X, const int4* tab, float* P, const GemmGeom& g, int splits,
+                         int pix_per_split, hipStream_t s) {
+  const int m_tiles = g.Mpad / BM, k_tiles = g.Kpad / BN;
+  hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P, g,
+                     m_tiles, k_tiles, pix_per_split);
+}
+
+}  // namespace dasac
+
+using namespace dasac;
+
+// M tile chosen from the padded channel count: 128 | 64 | 32
+static int pick_bm(int Mpad) { return Mpad % 128 == 0 ? 128 : (Mpad % 64 == 0 ? 64 : 32); }
+
+extern "C" int dasac_conv_mpad(int M) { return M > 64 ? (M + 127) / 128 * 128 : (M > 32 ? 64 : 32); }
+extern "C" int dasac_conv_kpad(int K) { return (K + 127) / 128 * 128; }
+
+extern "C" int dasac_conv_table(const int32_t* kh, const int32_t* kw, const int32_t* dil, const int32_t* pad,
+                                int n_branches, int C, int plane_h, int plane_w, int transposed, int32_t* table,
+                                dasac_stream_t stream) {
+  DASAC_REQUIRE(kh && kw && dil && pad && table, "conv_table: null pointer");
+  DASAC_REQUIRE(n_branches >= 1 && n_branches <= 4 && C > 0, "conv_table: bad branches/C");
+  TapGroups tg;
+  tg.n = n_branches;
+  int taps = 0;
+  for (int b = 0; b < n_branches; ++b) {
+    tg.kh[b] = kh[b]; tg.kw[b] = kw[b]; tg.dil[b] = dil[b]; tg.pad[b] = pad[b];
+    taps += kh[b] * kw[b];
+  }
+  for (int b = n_branches; b < 4; ++b) tg.kh[b] = tg.kw[b] = tg.dil[b] = tg.pad[b] = 1;
+  const int K = taps * C, Kpad = dasac_conv_kpad(K);
+  hipLaunchKernelGGL(build_table, dim3((Kpad + 255) / 256), dim3(256), 0, as_stream(stream), reinterpret_cast<int4*>(table),
+                     tg, C, K, Kpad, plane_h * plane_w, plane_w, transposed ? -1 : 1);
+  DASAC_CHECK_LAUNCH("build_table");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_conv_pack(const float* w, const float* scale, int Cout, int Cin, int taps, int tap0, int total_taps,
+                               int transposed, float* packed, dasac_stream_t stream) {
+  DASAC_REQUIRE(w && packed, "conv_pack: null pointer");
+  const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
+  const int Mpad = dasac_conv_mpad(M), K = total_taps * C, Kpad = dasac_conv_kpad(K);
+  hipStream_t s = as_stream(stream);
+  if (tap0 == 0 && Kpad > K) DASAC_HIP(hipMemsetAsync(packed + (size_t)K * Mpad, 0, (size_t)(Kpad - K) * Mpad * sizeof(float), s));
+  const int64_t total = (int64_t)taps * C * Mpad;
+  hipLaunchKernelGGL(pack_weights, dim3(stream_grid(total, 256)), dim3(256), 0, s, w, scale, packed, Cout, Cin, taps, tap0,
+                     Mpad, transposed ? 1 : 0);
+  DASAC_CHECK_LAUNCH("pack_weights");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx,
+                               int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
+                               const float* scale, const float* shift, const float* res, const float* mask, int relu,
+                               dasac_stream_t stream) {
+  DASAC_REQUIRE(x && packed && table && out, "conv_gemm: null pointer");
+  GemmGeom g;
+  const int Mpad = dasac_conv_mpad(M), Kloop = (K + kBK - 1) / kBK * kBK;   // table/pack are padded to 128 >= Kloop
+  int rc = fill_geom(g, Nb, Cx, H, W, OH, OW, stride, M, Mpad, Kloop, OutH, OutW, ostride);
+  if (rc) return rc;
+  Epilogue ep{scale, shift, res, mask, relu};
+  const int4* tab = reinterpret_cast<const int4*>(table);
+  hipStream_t s = as_stream(stream);
+  switch (pick_bm(Mpad)) {
+    case 128: launch_gemm<128, 128, 2>(x, packed, tab, out, g, ep, s); break;
+    case 64: launch_gemm<64, 128, 2>(x, packed, tab, out, g, ep, s); break;
+    default: launch_gemm<32, 256, 1>(x, packed, tab, out, g, ep, s); break;
+  }
+  DASAC_CHECK_LAUNCH("conv_gemm");
+  return DASAC_OK;
+}
+
+static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM) {
+  const int tiles = (Mpad / BM) * (Kpad / 128);
+  int splits = (kNumCu * 4 + tiles - 1) / tiles;            // aim at >= 4 blocks per CU
+  const int max_splits = (Npix + 1023) / 1024;              // at least 1024 pixels per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+extern "C" size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K) {
+  const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
+  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
+  return (size_t)splits * Mpad * Kpad * sizeof(float);
+}
+
+// dz [Nb,M,OH,OW], x [Nb,Cx,H,W] -> slabs in workspace -> dW (one or several weight tensors of a fused conv)
+extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table, int Nb, int Cx, int H, int W, int OH,
+                                int OW, int stride, int M, int K, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  DASAC_REQUIRE(dz && x && table && workspace, "conv_wgrad: null pointer");
+  GemmGeom g;
+  const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
+  int rc = fill_geom(g, Nb, Cx, H, W, OH, OW, stride, M, Mpad, Kpad, OH, OW, 1);
+  if (rc) return rc;
+  const int bm = pick_bm(Mpad);
+  const int splits = wgrad_splits(Mpad, Kpad, g.Npix, bm);
+  if (ws_bytes < (size_t)splits * Mpad * Kpad * sizeof(float)) return fail(DASAC_EWORKSPACE, "conv_wgrad: workspace too small");
+  int per = (g.Npix + splits - 1) / splits;
+  per = (per + kWgPix - 1) / kWgPix * kWgPix;
+  const int4* tab = reinterpret_cast<const int4*>(table);
+  float* P = reinterpret_cast<float*>(workspace);
+  hipStream_t s = as_stream(stream);
+  switch (bm) {
+    case 128: launch_wgrad<128, 128, 2>(dz, x, tab, P, g, splits, per, s); break;
+    case 64: launch_wgrad<64, 128, 2>(dz, x, tab, P, g, splits, per, s); break;
+    default: launch_wgrad<32, 128, 1>(dz, x, tab, P, g, splits, per, s); break;
+  }
+  DASAC_CHECK_LAUNCH("conv_wgrad");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K, const float* w,
+                                       const float* scale, float* dw, float* dot, int Cin, int taps, int tap0,
+                                       dasac_stream_t stream) {
+  DASAC_REQUIRE(workspace && w && dw, "conv_wgrad_finish: null pointer");
+  const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
+  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
+  hipLaunchKernelGGL(wgrad_reduce, dim3(M), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(workspace), splits,
+                     Mpad, Kpad, w, scale, dw, dot, Cin, taps, tap0);
+  DASAC_CHECK_LAUNCH("wgrad_reduce");
+  return DASAC_OK;
+}

@@ -16,6 +16,14 @@ PROTOTYPES = {
     "dasac_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
     "dasac_pseudo_labels_workspace": (_sz, [_i, _i, _l]),
     "dasac_pseudo_labels": (_i, [_p, _p, _p, _f, _f, _i, _i, _l, _p, _p, _p, _p, _sz, _p]),
+    "dasac_conv_mpad": (_i, [_i]),
+    "dasac_conv_kpad": (_i, [_i]),
+    "dasac_conv_table": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_conv_pack": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_conv_gemm": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _i, _p]),
+    "dasac_conv_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "dasac_conv_wgrad": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
+    "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 
 

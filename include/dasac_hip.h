@@ -53,6 +53,45 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
                         int64_t* labels, float* max_conf, int64_t* max_idx,
                         void* workspace, size_t ws_bytes, dasac_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Convolutions as implicit GEMM on fp32 MFMA -- every nn.Conv2d of models/deeplabv2.py
+ * (:59,65-66,70,107,122,147-148,262-263) and models/fcn.py (:49,53,57,78,88), with the
+ * BN(eval)/bias/residual/ReLU chain of Bottleneck.forward (deeplabv2.py:79-99) in the epilogue.
+ *
+ * A convolution is described by "tap branches" (kh,kw,dilation,padding): one branch for a plain
+ * conv, four for the ASPP sum of deeplabv2.py:112-116 evaluated as a single contraction.
+ *   K = (sum of kh*kw) * C,  k = tap*C + c (tap-major).
+ * dasac_conv_table   builds the gather table [Kpad][4] int32 for planes of plane_h x plane_w;
+ *                    transposed=1 gives the data-gradient geometry (C = Cout, dh = pad - kh*dil).
+ * dasac_conv_pack    lays W [Cout,Cin,kh,kw] out as [Kpad][Mpad] (transposed=1: rows (tap,co),
+ *                    columns ci, optionally scaled per co by `scale` = folded BN gamma*invstd).
+ *                    Call once per branch (tap0 = first tap of the branch, total_taps = all).
+ * dasac_conv_gemm    out[n,m,oh*os,ow*os] = epi( sum_k packed[k][m] * x[n, c, oh*stride+dh, ow*stride+dw] )
+ *                    epi: v*scale[m] + shift[m] (+res) (ReLU) (zeroed where mask <= 0).
+ * dasac_conv_wgrad   partial weight gradients (split over pixels) into `workspace`;
+ * dasac_conv_wgrad_finish  sums the splits, writes dW[co,ci,kh,kw] = scale[co]*G and, when `dot`
+ *                    is given, dot[co] += sum_k W*G (the frozen-BN gamma gradient term).
+ */
+int dasac_conv_mpad(int M);
+int dasac_conv_kpad(int K);
+int dasac_conv_table(const int32_t* kh, const int32_t* kw, const int32_t* dil, const int32_t* pad,
+                     int n_branches, int C, int plane_h, int plane_w, int transposed,
+                     int32_t* table, dasac_stream_t stream);
+int dasac_conv_pack(const float* w, const float* scale, int Cout, int Cin, int taps, int tap0,
+                    int total_taps, int transposed, float* packed, dasac_stream_t stream);
+int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out,
+                    int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
+                    int OutH, int OutW, int ostride,
+                    const float* scale, const float* shift, const float* res, const float* mask,
+                    int relu, dasac_stream_t stream);
+size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K);
+int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
+                     int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
+                     void* workspace, size_t ws_bytes, dasac_stream_t stream);
+int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K,
+                            const float* w, const float* scale, float* dw, float* dot,
+                            int Cin, int taps, int tap0, dasac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

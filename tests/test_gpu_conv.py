@@ -1,0 +1,132 @@
+"""Implicit-GEMM convolution kernels (forward / data-gradient / weight-gradient) against ATen CPU
+conv2d + autograd (the oracle's conv arithmetic), through the C ABI.  Tolerance: 1e-3 relative to
+the tensor's max magnitude (BASELINE.json north_star), in practice ~1e-6."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = [
+    # name, cin, cout, branches[(kh,kw,dil,pad)], stride, (N,H,W)
+    ("1x1", 64, 256, [(1, 1, 1, 0)], 1, (2, 25, 33)),
+    ("1x1_s2", 256, 128, [(1, 1, 1, 0)], 2, (2, 25, 33)),
+    ("3x3_d2", 32, 64, [(3, 3, 2, 2)], 1, (2, 19, 23)),
+    ("3x3_d4_big", 128, 128, [(3, 3, 4, 4)], 1, (1, 33, 31)),
+    ("3x3_d1_c19", 48, 19, [(3, 3, 1, 1)], 1, (3, 9, 13)),
+    ("7x7_s2_stem", 3, 64, [(7, 7, 1, 3)], 2, (2, 65, 49)),
+    ("aspp4", 96, 19, [(3, 3, 6, 6), (3, 3, 12, 12), (3, 3, 18, 18), (3, 3, 24, 24)], 1, (2, 17, 21)),
+    ("7x7_fcn_head", 16, 160, [(7, 7, 1, 3)], 1, (1, 8, 12)),
+]
+
+
+def _make(case, seed=0):
+    name, cin, cout, br, stride, (N, H, W) = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, cin, H, W, generator=g)
+    ws = [torch.randn(cout, cin, b[0], b[1], generator=g) / (cin * b[0] * b[1]) ** 0.5 for b in br]
+    return x, ws
+
+
+def _ref_forward(x, ws, br, stride):
+    out = None
+    for w, (kh, kw, d, p) in zip(ws, br):
+        o = F.conv2d(x, w, None, stride, p, d)
+        out = o if out is None else out + o
+    return out
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_forward_dgrad_wgrad(case):
+    from dasac_hip import ops
+    name, cin, cout, br, stride, _ = case
+    spec = ops.ConvSpec(cin, cout, br, stride)
+    x, ws = _make(case)
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    yr = _ref_forward(xr, wr, br, stride)
+    g = torch.Generator().manual_seed(1)
+    dz = torch.randn(yr.shape, generator=g)
+    yr.backward(dz)
+
+    xd, wd, dzd = x.cuda(), [w.cuda() for w in ws], dz.cuda()
+    y = ops.conv_forward(spec, xd, wd)
+    assert y.shape == yr.shape
+    assert rel_err(y, yr) < TOL
+    gw = ops.conv_wgrad(spec, dzd, xd, wd)
+    for a, b in zip(gw, wr):
+        assert rel_err(a, b.grad) < TOL
+    if stride == 1 or spec.taps == 1:
+        dx = ops.conv_dgrad(spec, dzd, wd, x.shape[2:])
+        assert rel_err(dx, xr.grad) < TOL
+
+
+def test_epilogue_bn_residual_relu_and_mask():
+    """y = relu(scale*conv + shift + res): the fused 'ABN' epilogue, and the masked dgrad epilogue."""
+    from dasac_hip import ops
+    case = ("e", 40, 72, [(3, 3, 2, 2)], 1, (2, 15, 18))
+    spec = ops.ConvSpec(40, 72, case[3], 1)
+    x, ws = _make(case, 3)
+    g = torch.Generator().manual_seed(4)
+    scale, shift = torch.rand(72, generator=g) + 0.5, torch.randn(72, generator=g)
+    res = torch.randn(2, 72, 15, 18, generator=g)
+    ref = F.relu(F.conv2d(x, ws[0], None, 1, 2, 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    y = ops.conv_forward(spec, x.cuda(), [ws[0].cuda()], scale.cuda(), shift.cuda(), res.cuda(), relu=True)
+    assert rel_err(y, ref) < TOL
+    # dgrad with per-channel scale folded into the packed weights, accumulate + mask
+    dz = torch.randn(ref.shape, generator=g)
+    acc = torch.randn(x.shape, generator=g)
+    msk = torch.randn(x.shape, generator=g)
+    dref = F.conv_transpose2d(dz * scale.view(1, -1, 1, 1), ws[0], None, 1, 2, 0, 1, 2) + acc
+    dref = torch.where(msk > 0, dref, torch.zeros_like(dref))
+    dx = ops.conv_dgrad(spec, dz.cuda(), [ws[0].cuda()], x.shape[2:], scale=scale.cuda(), res=acc.cuda(), mask=msk.cuda())
+    assert rel_err(dx, dref) < TOL
+    # wgrad with scale and the gamma-gradient dot term
+    dot = torch.zeros(72, device="cuda")
+    (gw,) = ops.conv_wgrad(spec, dz.cuda(), x.cuda(), [ws[0].cuda()], scale=scale.cuda(), dot=dot)
+    xr, wr = x.clone(), ws[0].clone().requires_grad_(True)
+    z = F.conv2d(xr, wr, None, 1, 2, 2)
+    (z * scale.view(1, -1, 1, 1) * dz).sum().backward()
+    assert rel_err(gw, wr.grad) < TOL
+    assert rel_err(dot, (z.detach() * dz).sum((0, 2, 3))) < TOL
+
+
+def test_strided_1x1_dgrad_accumulates_off_lattice():
+    from dasac_hip import ops
+    spec = ops.ConvSpec(24, 40, [(1, 1, 1, 0)], 2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 24, 13, 17, generator=g, requires_grad=True)
+    w = torch.randn(40, 24, 1, 1, generator=g)
+    y = F.conv2d(x, w, None, 2)
+    dz = torch.randn(y.shape, generator=g)
+    y.backward(dz)
+    acc = torch.randn(x.shape, generator=g)
+    dx = ops.conv_dgrad(spec, dz.cuda(), [w.cuda()], (13, 17), res=acc.cuda())
+    assert rel_err(dx, x.grad + acc) < TOL
+
+
+def test_resnet_shapes_full_size_linearity():
+    """cfg-3 layer3 shape [8,256,97,97] 3x3 d2: too big for the CPU oracle in seconds, so check
+    linearity conv(a*x1 + x2) == a*conv(x1) + conv(x2) and a sampled direct evaluation."""
+    from dasac_hip import ops
+    spec = ops.ConvSpec(256, 256, [(3, 3, 2, 2)], 1)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x1 = torch.randn(8, 256, 97, 97, device="cuda", generator=g)
+    x2 = torch.randn(8, 256, 97, 97, device="cuda", generator=g)
+    w = torch.randn(256, 256, 3, 3, device="cuda", generator=g) / 48
+    table = ops.conv_table(spec, 97, 97, False, x1.device)
+    packed = ops.conv_pack(spec, [w], False)
+    y1 = ops.conv_forward(spec, x1, [w], table=table, packed=packed)
+    y2 = ops.conv_forward(spec, x2, [w], table=table, packed=packed)
+    y3 = ops.conv_forward(spec, 0.5 * x1 + x2, [w], table=table, packed=packed)
+    assert rel_err(y3, 0.5 * y1 + y2) < 1e-5
+    # direct evaluation of 64 sampled outputs on the CPU in float64
+    xs, wc, yc = x1.cpu().double(), w.cpu().double(), y1.cpu()
+    xp = F.pad(xs, (2, 2, 2, 2))
+    for i in range(64):
+        n, co, oh, ow = i % 8, (37 * i) % 256, (11 * i) % 97, (29 * i + 3) % 97
+        patch = xp[n, :, oh:oh + 5:2, ow:ow + 5:2]
+        assert abs(float((patch * wc[co]).sum()) - float(yc[n, co, oh, ow])) < 1e-4

