@@ -1,0 +1,511 @@
+// The SAC head on MI355X: everything between the stride-8 logits and the losses.  All kernels are
+// HBM-bound streaming passes over [B,C,H,W] fp32 planes (C = 19): lanes run along pixels
+// (coalesced NCHW plane reads), the class dimension is a register loop.
+//
+//   upsample_softmax   models/deeplabv2.py:217, models/sac.py:275-282   bilinear(ac=True) [+softmax, prior sums, pad mask]
+//   upsample_bwd_x/y   transpose of the above (separable gather, deterministic)
+//   ce_loss            models/deeplabv2.py:223-224, models/sac.py:119-149  CE / focal CE(+conf) value and dlogits
+//   warp_pool          models/sac.py:289-305 + 238-269 / 218-236          affine warp of T views -> fused pooling
+//   warp_back          models/sac.py:309-311
+//   warp_affine        models/sac.py:295-296 (diagnostic frame warp)
+//   class_state        models/sac.py:104-117,120,151-152                  running class prior, discount, focal weights
+#include "common.hpp"
+
+namespace dasac {
+
+constexpr int kMaxC = 32;   // classes held in registers
+constexpr int kHB = 256;
+
+// ---- bilinear taps, align_corners=True (ATen upsample_bilinear2d: src = scale*dst) ----------
+struct Tap {
+  int i0, i1;
+  float w0, w1;
+};
+__device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
+  const float src = scale * (float)dst;
+  int i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  Tap t;
+  t.i0 = i0;
+  t.i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  t.w1 = src - (float)i0;
+  t.w0 = 1.f - t.w1;
+  return t;
+}
+
+// one thread per high-res pixel, loop over classes.  Optional outputs:
+//   up    [B,C,H,W]  upsampled logits
+//   probs [B,C,H,W]  softmax(up) * (ignore ? 0 : 1)
+//   csum  [C] double class sums of the UNMASKED softmax (running class prior, sac.py:108)
+__global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict__ x, int C, int h, int w, int H, int W,
+                                                        float sh, float sw, const uint8_t* __restrict__ ignore,
+                                                        float* __restrict__ up, float* __restrict__ probs,
+                                                        double* __restrict__ csum, int blocks_per_image) {
+  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
+  const int HW = H * W, hw = h * w;
+  const float* xb = x + (size_t)b * C * hw;
+  float acc[kMaxC];
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c) acc[c] = 0.f;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const int oy = p / W, ox = p - oy * W;
+    const Tap ty = tap_ac(oy, sh, h), tx = tap_ac(ox, sw, w);
+    const int o00 = ty.i0 * w + tx.i0, o01 = ty.i0 * w + tx.i1, o10 = ty.i1 * w + tx.i0, o11 = ty.i1 * w + tx.i1;
+    float v[kMaxC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) {
+      if (c < C) {
+        const float* pl = xb + (size_t)c * hw;
+        const float top = tx.w0 * pl[o00] + tx.w1 * pl[o01];
+        const float bot = tx.w0 * pl[o10] + tx.w1 * pl[o11];
+        v[c] = ty.w0 * top + ty.w1 * bot;
+        mx = fmaxf(mx, v[c]);
+      }
+    }
+    const size_t obase = (size_t)b * C * HW + p;
+    if (up) {
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) up[obase + (size_t)c * HW] = v[c];
+    }
+    if (probs || csum) {
+      float den = 0.f;
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) {
+          v[c] = expf(v[c] - mx);
+          den += v[c];
+        }
+      const float inv = 1.f / den;
+      const bool ign = ignore && ignore[(size_t)b * HW + p];
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) {
+          const float pr = v[c] * inv;
+          acc[c] += pr;
+          if (probs) probs[obase + (size_t)c * HW] = ign ? 0.f : pr;
+        }
+    }
+  }
+  if (csum) {
+    __shared__ double red[kHB / 64][kMaxC];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) {
+      if (c < C) {
+        const double s = wave_sum((double)acc[c]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = s;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+      double s = 0;
+      for (int wv = 0; wv < kHB / 64; ++wv) s += red[wv][threadIdx.x];
+      atomicAdd(&csum[threadIdx.x], s);
+    }
+  }
+}
+
+// ---- transpose of the bilinear upsampling, separable and gather-based (deterministic) ---------
+// pass X: tmp[plane][y][j] = sum_x wx(x->j) * g[plane][y][x]          (reads the big gradient once)
+// pass Y: d[plane][i][j]   = gscale * sum_y wy(y->i) * tmp[plane][y][j]
+__device__ __forceinline__ float weight_to(int dst, float scale, int n_in, int target) {
+  const Tap t = tap_ac(dst, scale, n_in);
+  float wgt = 0.f;
+  if (t.i0 == target) wgt += t.w0;
+  if (t.i1 == target) wgt += t.w1;   // i0 == i1 at the border: both weights land on the same source
+  return wgt;
+}
+__device__ __forceinline__ void src_range(int target, float scale, int n_out, int& lo, int& hi) {
+  // high-res positions whose taps can touch `target`:  target-1 < scale*dst < target+1
+  if (scale <= 0.f) {
+    lo = 0;
+    hi = n_out - 1;
+    return;
+  }
+  lo = (int)floorf((float)(target - 1) / scale) - 1;
+  hi = (int)ceilf((float)(target + 1) / scale) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > n_out - 1) hi = n_out - 1;
+}
+
+__global__ __launch_bounds__(kHB) void upsample_bwd_x(const float* __restrict__ g, int H, int W, int w, float sw,
+                                                      float* __restrict__ tmp, int64_t total) {
+  // total = planes*H*w; thread -> (plane, y, j), j fastest
+  for (int64_t i = (int64_t)blockIdx.x * kHB + threadIdx.x; i < total; i += (int64_t)gridDim.x * kHB) {
+    const int j = (int)(i % w);
+    const int64_t row = i / w;   // plane*H + y
+    int lo, hi;
+    src_range(j, sw, W, lo, hi);
+    const float* gr = g + row * W;
+    float s = 0.f;
+    for (int x = lo; x <= hi; ++x) s += weight_to(x, sw, w, j) * gr[x];
+    tmp[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(kHB) void upsample_bwd_y(const float* __restrict__ tmp, int H, int h, int w, float sh,
+                                                      const float* __restrict__ gscale, float* __restrict__ d,
+                                                      int64_t total) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * kHB + threadIdx.x; i < total; i += (int64_t)gridDim.x * kHB) {
+    const int j = (int)(i % w);
+    const int64_t r = i / w;
+    const int ii = (int)(r % h);
+    const int64_t plane = r / h;
+    int lo, hi;
+    src_range(ii, sh, H, lo, hi);
+    const float* tp = tmp + plane * H * w + j;
+    float s = 0.f;
+    for (int y = lo; y <= hi; ++y) s += weight_to(y, sh, h, ii) * tp[(size_t)y * w];
+    d[i] = s * gs;
+  }
+}
+
+// ---- cross entropy -------------------------------------------------------------------------
+// One thread per pixel, looping over the B images of that pixel (needed by the cross-batch product
+// of sac.py:148):   loss = sum_hw pw(hw) * sum_b ce_b(hw),
+//   mode 0  plain mean (deeplabv2.py:224, sac.py:132):  pw = 1/(B*HW)
+//   mode 1  focal_ce_conf (sac.py:148):                 pw = sum_i conf_i(hw) / (B*B*HW)
+// ce_b = -cw[y]*log_softmax(x)[y], 0 where y == 255.  dlogits (optional) = pw * cw[y] * (softmax - onehot).
+// per_class (optional, [C] double): sum over pixels of ce scattered by label (ignored -> class 0, value 0).
+__global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, const int64_t* __restrict__ y,
+                                               const float* __restrict__ cw, const float* __restrict__ conf, int B, int C,
+                                               int HW, int mode, float* __restrict__ dx, double* __restrict__ partial,
+                                               double* __restrict__ per_class) {
+  double lsum = 0.0;
+  __shared__ float s_pc[kMaxC];
+  if (per_class) {
+    if (threadIdx.x < kMaxC) s_pc[threadIdx.x] = 0.f;
+    __syncthreads();
+  }
+  const float norm = mode == 1 ? 1.f / ((float)B * (float)B * (float)HW) : 1.f / ((float)B * (float)HW);
+  for (int p = blockIdx.x * kHB + threadIdx.x; p < HW; p += gridDim.x * kHB) {
+    float cs = 1.f;
+    if (mode == 1) {
+      cs = 0.f;
+      for (int b = 0; b < B; ++b) cs += conf[(size_t)b * HW + p];
+    }
+    const float pw = cs * norm;
+    float cesum = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const size_t base = (size_t)b * C * HW + p;
+      const int64_t lab = y[(size_t)b * HW + p];
+      float v[kMaxC];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) {
+          v[c] = x[base + (size_t)c * HW];
+          mx = fmaxf(mx, v[c]);
+        }
+      float den = 0.f, xl = 0.f;
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) {
+          const float e = expf(v[c] - mx);
+          den += e;
+          if (c == lab) xl = v[c];
+          v[c] = e;
+        }
+      const bool valid = lab >= 0 && lab < C;   // 255 (ignore) and anything out of range carry no loss
+      const float wgt = valid ? (cw ? cw[lab] : 1.f) : 0.f;
+      const float ce = valid ? wgt * (logf(den) - (xl - mx)) : 0.f;
+      cesum += ce;
+      if (per_class && valid && ce != 0.f) atomicAdd(&s_pc[lab], ce);
+      if (dx) {
+        const float k = pw * wgt / den;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) dx[base + (size_t)c * HW] = k * v[c] - ((c == lab) ? pw * wgt : 0.f);
+      }
+    }
+    lsum += (double)pw * (double)cesum;
+  }
+  __shared__ double red[kHB / 64];
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (per_class && threadIdx.x < C && s_pc[threadIdx.x] != 0.f) atomicAdd(&per_class[threadIdx.x], (double)s_pc[threadIdx.x]);
+}
+
+__global__ void ce_finish(const double* __restrict__ partial, int n, float* __restrict__ loss,
+                          double* __restrict__ per_class, float* __restrict__ per_class_out, int C, double pc_norm) {
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss[0] = (float)s;
+  if (per_class_out && threadIdx.x < C) per_class_out[threadIdx.x] = (float)(per_class[threadIdx.x] * pc_norm);
+}
+
+// ---- affine warps: affine_grid + grid_sample(bilinear, zeros, align_corners=False) -------------
+struct Sample {
+  int o00, o01, o10, o11;     // flat offsets (clamped)
+  float w00, w01, w10, w11;   // weights, 0 when the corner is out of bounds
+};
+__device__ __forceinline__ Sample make_sample(const float* __restrict__ th, int oy, int ox, int H, int W) {
+  const float xb = (2.f * (float)ox + 1.f) / (float)W - 1.f;
+  const float yb = (2.f * (float)oy + 1.f) / (float)H - 1.f;
+  const float gx = th[0] * xb + th[1] * yb + th[2];
+  const float gy = th[3] * xb + th[4] * yb + th[5];
+  const float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+  const float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix;
+  const float wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
+  // keep the integer conversion safe for wild thetas
+  const float xc = fminf(fmaxf(x0f, -2.f), (float)W + 1.f), yc = fminf(fmaxf(y0f, -2.f), (float)H + 1.f);
+  const int x0 = (int)xc, y0 = (int)yc, x1 = x0 + 1, y1 = y0 + 1;
+  const bool far = (xc != x0f) || (yc != y0f);
+  const bool vx0 = !far && x0 >= 0 && x0 < W, vx1 = !far && x1 >= 0 && x1 < W;
+  const bool vy0 = !far && y0 >= 0 && y0 < H, vy1 = !far && y1 >= 0 && y1 < H;
+  const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+  const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+  Sample s;
+  s.o00 = cy0 * W + cx0; s.o01 = cy0 * W + cx1; s.o10 = cy1 * W + cx0; s.o11 = cy1 * W + cx1;
+  s.w00 = (vx0 && vy0) ? wx0 * wy0 : 0.f;
+  s.w01 = (vx1 && vy0) ? wx1 * wy0 : 0.f;
+  s.w10 = (vx0 && vy1) ? wx0 * wy1 : 0.f;
+  s.w11 = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+  return s;
+}
+__device__ __forceinline__ float take(const float* __restrict__ pl, const Sample& s) {
+  return pl[s.o00] * s.w00 + pl[s.o01] * s.w01 + pl[s.o10] * s.w10 + pl[s.o11] * s.w11;
+}
+
+// generic warp of a [B,C,H,W] tensor (frames_aligned diagnostic)
+__global__ __launch_bounds__(kHB) void warp_affine(const float* __restrict__ x, const float* __restrict__ theta, int C,
+                                                   int H, int W, float* __restrict__ out, int blocks_per_image) {
+  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
+  const int HW = H * W;
+  const float* th = theta + b * 6;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const Sample s = make_sample(th, p / W, p % W, H, W);
+    for (int c = 0; c < C; ++c) {
+      const size_t pb = ((size_t)b * C + c) * HW;
+      out[pb + p] = take(x + pb, s);
+    }
+  }
+}
+
+// views -> reference frame -> pooled.  One thread per (group, pixel):
+//   a_t   = sample(probs[n*T+t], theta[n*T+t])                     (teacher_aligned, optional output)
+//   cov_t = coverage(theta_inv[n*T+t]) at this pixel               (sac.py:299-301, quirk 4)
+//   avg (mode 0):  S = sum_t a_t*cov_t ; Z = sum_c S ; mask = Z > tol ; S /= max(Z, 1e-3)
+//   minentropy (mode 1): S = a_t*cov_t of the view with the lowest entropy (first minimum)
+__global__ __launch_bounds__(kHB) void warp_pool(const float* __restrict__ probs, const float* __restrict__ theta,
+                                                 const float* __restrict__ theta_inv, int T, int C, int H, int W,
+                                                 int mode, float tol, float* __restrict__ aligned,
+                                                 float* __restrict__ pooled, float* __restrict__ mask,
+                                                 int blocks_per_group) {
+  const int n = blockIdx.x / blocks_per_group, chunk = blockIdx.x % blocks_per_group;
+  const int HW = H * W;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_group * kHB) {
+    const int oy = p / W, ox = p - oy * W;
+    float S[kMaxC];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) S[c] = 0.f;
+    float best_ent = INFINITY, zsum = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const int b = n * T + t;
+      const Sample s = make_sample(theta + b * 6, oy, ox, H, W);
+      const Sample si = make_sample(theta_inv + b * 6, oy, ox, H, W);
+      const float cov = si.w00 + si.w01 + si.w10 + si.w11;
+      float v[kMaxC];
+      float vs = 0.f;
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) {
+          const size_t pb = ((size_t)b * C + c) * HW;
+          const float a = take(probs + pb, s);
+          if (aligned) aligned[pb + p] = a;
+          v[c] = a * cov;
+          vs += v[c];
+        }
+      if (mode == 0) {
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) S[c] += v[c];
+      } else {
+        // sac.py:189-196 entropy with eps = 1e-5; empty pixels get 1/eps
+        float ent = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) ent -= v[c] * logf((v[c] + 1e-5f) / (1.f + 1e-5f));
+        if (vs < 0.1f) ent = 1.f / 1e-5f;
+        zsum += vs;
+        if (ent < best_ent) {
+          best_ent = ent;
+#pragma unroll
+          for (int c = 0; c < kMaxC; ++c)
+            if (c < C) S[c] = v[c];
+        }
+      }
+    }
+    float m;
+    if (mode == 0) {
+      float Z = 0.f;
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) Z += S[c];
+      m = Z > tol ? 1.f : 0.f;
+      const float den = fmaxf(Z, 1e-3f);
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < C) S[c] = S[c] / den;
+    } else {
+      m = zsum > tol ? 1.f : 0.f;
+    }
+    mask[(size_t)n * HW + p] = m;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) pooled[((size_t)n * C + c) * HW + p] = S[c];
+  }
+}
+
+// refined[b] = sample(pooled[g(b)], theta_inv[b]) * sample(mask[g(b)], theta_inv[b]),  g(b) = group_of[b]
+__global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ pooled, const float* __restrict__ mask,
+                                                 const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
+                                                 float* __restrict__ refined, int blocks_per_image) {
+  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
+  const int n = b / group_div;
+  const int HW = H * W;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const Sample s = make_sample(theta_inv + b * 6, p / W, p % W, H, W);
+    const float mv = take(mask + (size_t)n * HW, s);
+    for (int c = 0; c < C; ++c)
+      refined[((size_t)b * C + c) * HW + p] = take(pooled + ((size_t)n * C + c) * HW, s) * mv;
+  }
+}
+
+// ---- class prior state (19 floats; one wave) ------------------------------------------------------
+// chi update (sac.py:104-117) from the class sums of this batch, then the two derived vectors:
+//   disc = 1 - exp(-chi/beta) (sac.py:152), focal = (1 - max(chi,0))^p (sac.py:120,135)
+__global__ void class_state(float* __restrict__ chi, const double* __restrict__ csum, double count_hw, int B, int C,
+                            float beta, float momentum, float tolerance, int update, float focal_p,
+                            float* __restrict__ disc, float* __restrict__ focal) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float v = chi[c];
+  if (update) {
+    // probs.mean(0).view(C,-1).mean(-1): mean over the batch, then over pixels
+    const float avg = (float)((csum[c] / (double)B) / count_hw);
+    if (avg > tolerance && v == beta) v = avg;
+    v = v * momentum;
+    v = v + (1.f - momentum) * avg;
+    chi[c] = v;
+  }
+  if (disc) disc[c] = 1.f - expf(-(v / beta));
+  if (focal) {
+    const float base = 1.f - fmaxf(v, 0.f);
+    float r;
+    if (focal_p == 3.f) r = base * base * base;
+    else if (focal_p == 2.f) r = base * base;
+    else if (focal_p == 1.f) r = base;
+    else r = powf(base, focal_p);
+    focal[c] = r;
+  }
+}
+
+}  // namespace dasac
+
+using namespace dasac;
+
+static float ac_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }
+
+extern "C" int dasac_upsample_softmax(const float* logits, int B, int C, int h, int w, int H, int W,
+                                      const uint8_t* ignore, float* up, float* probs, double* class_sums,
+                                      dasac_stream_t stream) {
+  DASAC_REQUIRE(logits && (up || probs || class_sums), "upsample_softmax: null pointer");
+  DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && h > 0 && w > 0 && H > 0 && W > 0, "upsample_softmax: bad shape");
+  hipStream_t s = as_stream(stream);
+  if (class_sums) DASAC_HIP(hipMemsetAsync(class_sums, 0, C * sizeof(double), s));
+  const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
+  hipLaunchKernelGGL(upsample_softmax, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), ac_scale(w, W),
+                     ignore, up, probs, class_sums, per);
+  DASAC_CHECK_LAUNCH("upsample_softmax");
+  return DASAC_OK;
+}
+
+extern "C" size_t dasac_upsample_bwd_workspace(int planes, int H, int w) { return (size_t)planes * H * w * sizeof(float); }
+
+extern "C" int dasac_upsample_bwd(const float* grad_up, int planes, int h, int w, int H, int W, const float* gscale,
+                                  float* grad_low, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  DASAC_REQUIRE(grad_up && grad_low && workspace, "upsample_bwd: null pointer");
+  if (ws_bytes < dasac_upsample_bwd_workspace(planes, H, w)) return fail(DASAC_EWORKSPACE, "upsample_bwd: workspace too small");
+  hipStream_t s = as_stream(stream);
+  float* tmp = reinterpret_cast<float*>(workspace);
+  const int64_t t1 = (int64_t)planes * H * w, t2 = (int64_t)planes * h * w;
+  hipLaunchKernelGGL(upsample_bwd_x, dim3(stream_grid(t1, kHB)), dim3(kHB), 0, s, grad_up, H, W, w, ac_scale(w, W), tmp, t1);
+  DASAC_CHECK_LAUNCH("upsample_bwd_x");
+  hipLaunchKernelGGL(upsample_bwd_y, dim3(stream_grid(t2, kHB)), dim3(kHB), 0, s, tmp, H, h, w, ac_scale(h, H), gscale, grad_low, t2);
+  DASAC_CHECK_LAUNCH("upsample_bwd_y");
+  return DASAC_OK;
+}
+
+static int ce_blocks(int64_t HW) { return stream_grid(HW, kHB, kNumCu * 8); }
+
+extern "C" size_t dasac_ce_loss_workspace(int B, int C, int64_t HW) {
+  return align_up((size_t)ce_blocks(HW) * sizeof(double), 256) + align_up((size_t)kMaxC * sizeof(double), 256);
+}
+
+extern "C" int dasac_ce_loss(const float* logits, const int64_t* labels, const float* class_weight, const float* conf,
+                             int B, int C, int64_t HW, int mode, float* loss, float* dlogits, float* per_class,
+                             void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  DASAC_REQUIRE(logits && labels && loss && workspace, "ce_loss: null pointer");
+  DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && HW > 0 && HW < (1ll << 31) && (mode == 0 || (mode == 1 && conf)), "ce_loss: bad arguments");
+  if (ws_bytes < dasac_ce_loss_workspace(B, C, HW)) return fail(DASAC_EWORKSPACE, "ce_loss: workspace too small");
+  hipStream_t s = as_stream(stream);
+  const int blocks = ce_blocks(HW);
+  double* partial = reinterpret_cast<double*>(workspace);
+  double* pc = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)blocks * sizeof(double), 256));
+  if (per_class) DASAC_HIP(hipMemsetAsync(pc, 0, kMaxC * sizeof(double), s));
+  hipLaunchKernelGGL(ce_loss, dim3(blocks), dim3(kHB), 0, s, logits, labels, class_weight, conf, B, C, (int)HW, mode, dlogits,
+                     partial, per_class ? pc : nullptr);
+  DASAC_CHECK_LAUNCH("ce_loss");
+  hipLaunchKernelGGL(ce_finish, dim3(1), dim3(64), 0, s, partial, blocks, loss, pc, per_class, C, 1.0 / ((double)HW * B));
+  DASAC_CHECK_LAUNCH("ce_finish");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_warp_affine(const float* x, const float* theta, int B, int C, int H, int W, float* out,
+                                 dasac_stream_t stream) {
+  DASAC_REQUIRE(x && theta && out && B > 0 && C > 0 && H > 0 && W > 0, "warp_affine: bad arguments");
+  const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
+  hipLaunchKernelGGL(warp_affine, dim3(per * B), dim3(kHB), 0, as_stream(stream), x, theta, C, H, W, out, per);
+  DASAC_CHECK_LAUNCH("warp_affine");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_warp_pool(const float* probs, const float* theta, const float* theta_inv, int N, int T, int C, int H,
+                               int W, int mode, float tolerance, float* aligned, float* pooled, float* mask,
+                               dasac_stream_t stream) {
+  DASAC_REQUIRE(probs && theta && theta_inv && pooled && mask, "warp_pool: null pointer");
+  DASAC_REQUIRE(N > 0 && T > 0 && C > 0 && C <= kMaxC && (mode == 0 || mode == 1), "warp_pool: bad arguments");
+  const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + N - 1) / N);
+  hipLaunchKernelGGL(warp_pool, dim3(per * N), dim3(kHB), 0, as_stream(stream), probs, theta, theta_inv, T, C, H, W, mode,
+                     tolerance, aligned, pooled, mask, per);
+  DASAC_CHECK_LAUNCH("warp_pool");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_warp_back(const float* pooled, const float* mask, const float* theta_inv, int B, int views_per_group,
+                               int C, int H, int W, float* refined, dasac_stream_t stream) {
+  DASAC_REQUIRE(pooled && mask && theta_inv && refined && B > 0 && views_per_group > 0, "warp_back: bad arguments");
+  const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
+  hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
+                     W, refined, per);
+  DASAC_CHECK_LAUNCH("warp_back");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_class_state(float* running_conf, const double* class_sums, int B, int64_t HW, int C, float beta,
+                                 float stat_momentum, int update, float focal_p, float* disc, float* focal,
+                                 dasac_stream_t stream) {
+  DASAC_REQUIRE(running_conf && C > 0 && C <= 64 && (!update || class_sums), "class_state: bad arguments");
+  hipLaunchKernelGGL(class_state, dim3(1), dim3(64), 0, as_stream(stream), running_conf, class_sums, (double)HW, B, C, beta,
+                     stat_momentum, 1e-8f, update, focal_p, disc, focal);
+  DASAC_CHECK_LAUNCH("class_state");
+  return DASAC_OK;
+}

@@ -1,0 +1,255 @@
+// Small HBM-bound helpers around the conv GEMMs: frozen-BN folding and parameter gradients,
+// max-pooling, per-channel reductions, the momentum-teacher multi-tensor update, Dropout2d scaling.
+#include "common.hpp"
+
+namespace dasac {
+
+// ---- frozen BatchNorm (eval mode; models/__init__.py:29 + models/basenet.py:97-100) -------------
+// ATen eval batch_norm: invstd = 1/sqrt(var+eps); alpha = gamma*invstd; beta' = beta - mean*alpha
+__global__ void bn_fold(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                        const float* __restrict__ var, const float* __restrict__ conv_bias, float eps, int C,
+                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(var[c] + eps);
+  const float a = gamma[c] * is;
+  const float m = conv_bias ? mean[c] - conv_bias[c] : mean[c];   // BN(conv + b) = a*conv + (beta - (mean-b)*a)
+  scale[c] = a;
+  shift[c] = beta[c] - m * a;
+  if (invstd) invstd[c] = is;
+}
+
+// dgamma = invstd*(dot + (b - mean)*sum_dz), dbeta = sum_dz, dbias_conv = scale*sum_dz
+__global__ void bn_param_grads(const float* __restrict__ dot, const float* __restrict__ sum_dz, const float* __restrict__ mean,
+                               const float* __restrict__ invstd, const float* __restrict__ scale,
+                               const float* __restrict__ conv_bias, int C, float* __restrict__ dgamma,
+                               float* __restrict__ dbeta, float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = sum_dz[c];
+  const float b = conv_bias ? conv_bias[c] : 0.f;
+  if (dgamma) dgamma[c] = invstd[c] * (dot[c] + (b - mean[c]) * s);
+  if (dbeta) dbeta[c] = s;
+  if (dbias) dbias[c] = (scale ? scale[c] : 1.f) * s;
+}
+
+// out[c] = sum_{n,p} x[n,c,p]; one block per channel
+__global__ __launch_bounds__(256) void channel_sums(const float* __restrict__ x, int N, int C, int HW, float* __restrict__ out) {
+  const int c = blockIdx.x;
+  double s = 0;
+  for (int n = 0; n < N; ++n) {
+    const float* p = x + ((size_t)n * C + c) * HW;
+    float part = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) part += p[i];
+    s += part;
+  }
+  __shared__ double red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- max pooling (deeplabv2.py:126 3x3/2 pad 1 ceil_mode; torchvision VGG 2x2/2) -------------------
+// forward also records the argmax position inside the window (kh*k + kw), first maximum wins.
+__global__ __launch_bounds__(256) void maxpool_fwd(const float* __restrict__ x, int H, int W, int OH, int OW, int k, int s,
+                                                   int pad, float* __restrict__ y, uint8_t* __restrict__ arg,
+                                                   int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(i % OW);
+    const int64_t r = i / OW;
+    const int oh = (int)(r % OH);
+    const int64_t plane = r / OH;
+    const float* xp = x + plane * H * W;
+    float best = -INFINITY;
+    int code = 0;
+    for (int a = 0; a < k; ++a) {
+      const int ih = oh * s - pad + a;
+      if (ih < 0 || ih >= H) continue;
+      for (int b = 0; b < k; ++b) {
+        const int iw = ow * s - pad + b;
+        if (iw < 0 || iw >= W) continue;
+        const float v = xp[ih * W + iw];
+        if (v > best || v != v) {
+          best = v;
+          code = a * k + b;
+        }
+      }
+    }
+    y[i] = best;
+    arg[i] = (uint8_t)code;
+  }
+}
+
+// dx[ih,iw] = sum over windows o containing (ih,iw) with argmax(o) == this position of dy(o)
+// relu_mask: additionally require y(o) > 0 -- the pooled tensor is ReLU output, so this is exactly
+// the ReLU backward of the producer folded in (no need to keep the un-pooled activation).
+__global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                   const uint8_t* __restrict__ arg, int H, int W, int OH, int OW, int k,
+                                                   int s, int pad, int relu_mask, float* __restrict__ dx, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int iw = (int)(i % W);
+    const int64_t r = i / W;
+    const int ih = (int)(r % H);
+    const int64_t plane = r / H;
+    const size_t ob = (size_t)plane * OH * OW;
+    // windows: oh*s - pad <= ih <= oh*s - pad + k - 1
+    int oh_lo = (ih + pad - k + 1 + s - 1) / s, oh_hi = (ih + pad) / s;
+    int ow_lo = (iw + pad - k + 1 + s - 1) / s, ow_hi = (iw + pad) / s;
+    if (ih + pad - k + 1 < 0) oh_lo = 0;
+    if (iw + pad - k + 1 < 0) ow_lo = 0;
+    if (oh_hi > OH - 1) oh_hi = OH - 1;
+    if (ow_hi > OW - 1) ow_hi = OW - 1;
+    float g = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int code = (ih - (oh * s - pad)) * k + (iw - (ow * s - pad));
+        const size_t o = ob + (size_t)oh * OW + ow;
+        if (arg[o] == code && (!relu_mask || y[o] > 0.f)) g += dy[o];
+      }
+    dx[i] = g;
+  }
+}
+
+// ---- momentum teacher (models/sac.py:83-102) as one multi-tensor launch --------------------------
+// chunk table: for chunk i, tensor id + element offset.  sq[tensor] += sum (slow-fast)^2 (pre-update);
+// if update: slow = slow*m + fast*(1-m).
+struct TensorPair {
+  const float* fast;
+  float* slow;
+  int64_t n;
+};
+constexpr int kEmaChunk = 256 * 16;
+
+__global__ __launch_bounds__(256) void ema_chunks(const TensorPair* __restrict__ pairs, const int2* __restrict__ chunks,
+                                                  float momentum, float one_minus, int update, double* __restrict__ sq) {
+  const int2 ch = chunks[blockIdx.x];
+  const TensorPair tp = pairs[ch.x];
+  const int64_t base = (int64_t)ch.y * kEmaChunk;
+  double acc = 0;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i < tp.n) {
+      const float f = tp.fast[i], sl = tp.slow[i];
+      const float d = sl - f;
+      acc += (double)d * (double)d;
+      if (update) {
+        float v = sl * momentum;
+        v = v + f * one_minus;
+        tp.slow[i] = v;
+      }
+    }
+  }
+  __shared__ double red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&sq[ch.x], red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void ema_finish(const double* __restrict__ sq, int n, float* __restrict__ out) {
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 64) s += sqrt(sq[i]);
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+// y[n,c,:] = x[n,c,:] * m[n,c]   (Dropout2d with an explicit keep/(1-p) mask, fcn.py:52,56)
+__global__ __launch_bounds__(256) void scale_planes(const float* __restrict__ x, const float* __restrict__ m, int HW,
+                                                    float* __restrict__ y, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    y[i] = x[i] * m[i / HW];
+}
+
+// out = a + b (gradient joins); c = a*alpha elementwise helpers
+__global__ __launch_bounds__(256) void add2(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                            int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
+}  // namespace dasac
+
+using namespace dasac;
+
+extern "C" int dasac_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                             const float* conv_bias, float eps, int C, float* scale, float* shift, float* invstd,
+                             dasac_stream_t stream) {
+  DASAC_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, "bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta, mean, var, conv_bias, eps, C,
+                     scale, shift, invstd);
+  DASAC_CHECK_LAUNCH("bn_fold");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_param_grads(const float* dot, const float* sum_dz, const float* mean, const float* invstd,
+                                    const float* scale, const float* conv_bias, int C, float* dgamma, float* dbeta,
+                                    float* dbias, dasac_stream_t stream) {
+  DASAC_REQUIRE(sum_dz && C > 0 && (!dgamma || (dot && mean && invstd)), "bn_param_grads: bad arguments");
+  hipLaunchKernelGGL(bn_param_grads, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), dot, sum_dz, mean, invstd, scale,
+                     conv_bias, C, dgamma, dbeta, dbias);
+  DASAC_CHECK_LAUNCH("bn_param_grads");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_channel_sums(const float* x, int N, int C, int64_t HW, float* out, dasac_stream_t stream) {
+  DASAC_REQUIRE(x && out && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31), "channel_sums: bad arguments");
+  hipLaunchKernelGGL(channel_sums, dim3(C), dim3(256), 0, as_stream(stream), x, N, C, (int)HW, out);
+  DASAC_CHECK_LAUNCH("channel_sums");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_maxpool_fwd(const float* x, int planes, int H, int W, int OH, int OW, int k, int s, int pad, float* y,
+                                 uint8_t* argmax, dasac_stream_t stream) {
+  DASAC_REQUIRE(x && y && argmax && planes > 0 && k > 0 && k <= 15 && s > 0, "maxpool_fwd: bad arguments");
+  const int64_t total = (int64_t)planes * OH * OW;
+  hipLaunchKernelGGL(maxpool_fwd, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, H, W, OH, OW, k, s, pad, y,
+                     argmax, total);
+  DASAC_CHECK_LAUNCH("maxpool_fwd");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t* argmax, int planes, int H, int W, int OH,
+                                 int OW, int k, int s, int pad, int relu_mask, float* dx, dasac_stream_t stream) {
+  DASAC_REQUIRE(dy && y && argmax && dx && planes > 0, "maxpool_bwd: bad arguments");
+  const int64_t total = (int64_t)planes * H * W;
+  hipLaunchKernelGGL(maxpool_bwd, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), dy, y, argmax, H, W, OH, OW, k,
+                     s, pad, relu_mask, dx, total);
+  DASAC_CHECK_LAUNCH("maxpool_bwd");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_ema_chunk_elems(void) { return kEmaChunk; }
+
+// pairs: device array of {fast*, slow*, int64 n} (24 bytes each); chunks: device array of int32 pairs
+// (tensor id, chunk index within the tensor); sq: device [n_tensors] doubles (scratch); out: device [1].
+extern "C" int dasac_ema_update(const void* pairs, int n_tensors, const int32_t* chunks, int n_chunks, float momentum,
+                                int update, double* sq, float* out, dasac_stream_t stream) {
+  DASAC_REQUIRE(pairs && chunks && sq && out && n_tensors > 0 && n_chunks > 0, "ema_update: bad arguments");
+  hipStream_t s = as_stream(stream);
+  DASAC_HIP(hipMemsetAsync(sq, 0, (size_t)n_tensors * sizeof(double), s));
+  // sac.py:95 multiplies by the python double (1. - momentum) cast to fp32
+  const float one_minus = (float)(1.0 - (double)momentum);
+  hipLaunchKernelGGL(ema_chunks, dim3(n_chunks), dim3(256), 0, s, reinterpret_cast<const TensorPair*>(pairs),
+                     reinterpret_cast<const int2*>(chunks), momentum, one_minus, update, sq);
+  DASAC_CHECK_LAUNCH("ema_chunks");
+  hipLaunchKernelGGL(ema_finish, dim3(1), dim3(64), 0, s, sq, n_tensors, out);
+  DASAC_CHECK_LAUNCH("ema_finish");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_scale_planes(const float* x, const float* plane_scale, int64_t planes, int64_t HW, float* y,
+                                  dasac_stream_t stream) {
+  DASAC_REQUIRE(x && plane_scale && y && planes > 0 && HW > 0, "scale_planes: bad arguments");
+  const int64_t total = planes * HW;
+  hipLaunchKernelGGL(scale_planes, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, plane_scale, (int)HW, y, total);
+  DASAC_CHECK_LAUNCH("scale_planes");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_add(const float* a, const float* b, float* out, int64_t n, dasac_stream_t stream) {
+  DASAC_REQUIRE(a && b && out && n > 0, "add: bad arguments");
+  hipLaunchKernelGGL(add2, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), a, b, out, n);
+  DASAC_CHECK_LAUNCH("add");
+  return DASAC_OK;
+}

@@ -23,6 +23,24 @@ PROTOTYPES = {
     "dasac_conv_gemm": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _i, _p]),
     "dasac_conv_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dasac_conv_wgrad": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
+    "dasac_upsample_softmax": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "dasac_upsample_bwd_workspace": (_sz, [_i, _i, _i]),
+    "dasac_upsample_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "dasac_ce_loss_workspace": (_sz, [_i, _i, _l]),
+    "dasac_ce_loss": (_i, [_p, _p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _sz, _p]),
+    "dasac_warp_affine": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "dasac_warp_pool": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "dasac_warp_back": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_class_state": (_i, [_p, _p, _i, _l, _i, _f, _f, _i, _f, _p, _p, _p]),
+    "dasac_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
+    "dasac_bn_param_grads": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "dasac_channel_sums": (_i, [_p, _i, _i, _l, _p, _p]),
+    "dasac_maxpool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "dasac_maxpool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_ema_chunk_elems": (_i, []),
+    "dasac_ema_update": (_i, [_p, _i, _p, _i, _f, _i, _p, _p, _p]),
+    "dasac_scale_planes": (_i, [_p, _p, _l, _l, _p, _p]),
+    "dasac_add": (_i, [_p, _p, _p, _l, _p]),
     "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

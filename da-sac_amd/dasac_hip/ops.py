@@ -148,3 +148,233 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None):
         grads.append(dw)
         tap0 += kh * kw
     return grads
+
+
+# ----------------------------------------------------------------------------------------------
+# SAC head
+# ----------------------------------------------------------------------------------------------
+def _f32(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def upsample_softmax(logits, size, ignore=None, want_up=True, want_probs=False, want_sums=False):
+    """bilinear(ac=True) upsampling [+ masked softmax + class sums].  Returns (up, probs, class_sums)."""
+    lib = L.load()
+    L.require_gpu(logits, ignore)
+    logits = _c(logits)
+    B, Cn, h, w = logits.shape
+    H, W = int(size[0]), int(size[1])
+    up = _f32((B, Cn, H, W), logits) if want_up else None
+    probs = _f32((B, Cn, H, W), logits) if want_probs else None
+    sums = torch.empty(Cn, dtype=torch.float64, device=logits.device) if want_sums else None
+    ign = None if ignore is None else _c(ignore).view(torch.uint8)
+    L.check(lib.dasac_upsample_softmax(logits.data_ptr(), B, Cn, h, w, H, W, L.ptr(ign), L.ptr(up), L.ptr(probs),
+                                       L.ptr(sums), L.stream_ptr()), "dasac_upsample_softmax")
+    return up, probs, sums
+
+
+def upsample_bwd(grad_up, low_hw, gscale=None):
+    lib = L.load()
+    L.require_gpu(grad_up, gscale)
+    grad_up = _c(grad_up)
+    B, Cn, H, W = grad_up.shape
+    h, w = low_hw
+    out = _f32((B, Cn, h, w), grad_up)
+    nbytes = lib.dasac_upsample_bwd_workspace(B * Cn, H, w)
+    ws = L.workspace(nbytes, grad_up.device)
+    L.check(lib.dasac_upsample_bwd(grad_up.data_ptr(), B * Cn, h, w, H, W, L.ptr(gscale), out.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), L.stream_ptr()), "dasac_upsample_bwd")
+    return out
+
+
+def ce_loss(logits_up, labels, class_weight=None, conf=None, want_grad=False, want_per_class=False):
+    """Returns (loss[1], dlogits or None, per_class or None); conf given -> focal_ce_conf broadcast form."""
+    lib = L.load()
+    L.require_gpu(logits_up, labels, class_weight, conf)
+    logits_up, labels = _c(logits_up), _c(labels)
+    B, Cn, H, W = logits_up.shape
+    HW = H * W
+    loss = _f32((1,), logits_up)
+    dl = torch.empty_like(logits_up) if want_grad else None
+    pc = _f32((Cn,), logits_up) if want_per_class else None
+    nbytes = lib.dasac_ce_loss_workspace(B, Cn, HW)
+    ws = L.workspace(nbytes, logits_up.device)
+    L.check(lib.dasac_ce_loss(logits_up.data_ptr(), labels.data_ptr(), L.ptr(class_weight), L.ptr(None if conf is None else _c(conf)),
+                              B, Cn, HW, 0 if conf is None else 1, loss.data_ptr(), L.ptr(dl), L.ptr(pc), ws.data_ptr(),
+                              ws.numel(), L.stream_ptr()), "dasac_ce_loss")
+    return loss, dl, pc
+
+
+def warp_affine(x, theta):
+    lib = L.load()
+    L.require_gpu(x, theta)
+    x, theta = _c(x), _c(theta)
+    B, Cn, H, W = x.shape
+    out = torch.empty_like(x)
+    L.check(lib.dasac_warp_affine(x.data_ptr(), theta.data_ptr(), B, Cn, H, W, out.data_ptr(), L.stream_ptr()), "dasac_warp_affine")
+    return out
+
+
+POOL_MODES = {"avg_pool": 0, "minentropy_pool": 1}
+
+
+def warp_pool(probs, theta, theta_inv, T, mode="avg_pool", tolerance=0.1, want_aligned=True):
+    """probs [N*T,C,H,W] -> (pooled [N,C,H,W], mask [N,1,H,W], aligned or None)."""
+    lib = L.load()
+    L.require_gpu(probs, theta, theta_inv)
+    probs, theta, theta_inv = _c(probs), _c(theta), _c(theta_inv)
+    NT, Cn, H, W = probs.shape
+    assert NT % T == 0
+    N = NT // T
+    pooled = _f32((N, Cn, H, W), probs)
+    mask = _f32((N, 1, H, W), probs)
+    aligned = torch.empty_like(probs) if want_aligned else None
+    L.check(lib.dasac_warp_pool(probs.data_ptr(), theta.data_ptr(), theta_inv.data_ptr(), N, T, Cn, H, W, POOL_MODES[mode],
+                                float(tolerance), L.ptr(aligned), pooled.data_ptr(), mask.data_ptr(), L.stream_ptr()),
+            "dasac_warp_pool")
+    return pooled, mask, aligned
+
+
+def warp_back(pooled, mask, theta_inv, views_per_group):
+    lib = L.load()
+    L.require_gpu(pooled, mask, theta_inv)
+    theta_inv = _c(theta_inv)
+    N, Cn, H, W = pooled.shape
+    B = theta_inv.shape[0]
+    assert B == N * views_per_group
+    out = _f32((B, Cn, H, W), pooled)
+    L.check(lib.dasac_warp_back(pooled.data_ptr(), mask.data_ptr(), theta_inv.data_ptr(), B, views_per_group, Cn, H, W,
+                                out.data_ptr(), L.stream_ptr()), "dasac_warp_back")
+    return out
+
+
+def class_state(running_conf, class_sums, B, HW, beta, stat_momentum, update, focal_p, want_disc=True, want_focal=True):
+    """In-place update of running_conf (when update) and the derived (disc, focal) vectors."""
+    lib = L.load()
+    L.require_gpu(running_conf, class_sums)
+    Cn = running_conf.numel()
+    disc = _f32((Cn,), running_conf) if want_disc else None
+    focal = _f32((Cn,), running_conf) if want_focal else None
+    L.check(lib.dasac_class_state(running_conf.data_ptr(), L.ptr(class_sums), int(B), int(HW), Cn, float(beta),
+                                  float(stat_momentum), int(bool(update)), float(focal_p), L.ptr(disc), L.ptr(focal),
+                                  L.stream_ptr()), "dasac_class_state")
+    return disc, focal
+
+
+# ----------------------------------------------------------------------------------------------
+# around the convolutions
+# ----------------------------------------------------------------------------------------------
+def bn_fold(gamma, beta, mean, var, eps, conv_bias=None, want_invstd=True):
+    lib = L.load()
+    L.require_gpu(gamma, beta, mean, var, conv_bias)
+    Cn = gamma.numel()
+    scale, shift = _f32((Cn,), gamma), _f32((Cn,), gamma)
+    invstd = _f32((Cn,), gamma) if want_invstd else None
+    L.check(lib.dasac_bn_fold(gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr(), L.ptr(conv_bias), float(eps),
+                              Cn, scale.data_ptr(), shift.data_ptr(), L.ptr(invstd), L.stream_ptr()), "dasac_bn_fold")
+    return scale, shift, invstd
+
+
+def bn_param_grads(dot, sum_dz, mean, invstd, scale, conv_bias, want_gamma=True, want_beta=True, want_bias=False):
+    lib = L.load()
+    Cn = sum_dz.numel()
+    dg = _f32((Cn,), sum_dz) if want_gamma else None
+    db = _f32((Cn,), sum_dz) if want_beta else None
+    dcb = _f32((Cn,), sum_dz) if want_bias else None
+    L.check(lib.dasac_bn_param_grads(L.ptr(dot), sum_dz.data_ptr(), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(conv_bias),
+                                     Cn, L.ptr(dg), L.ptr(db), L.ptr(dcb), L.stream_ptr()), "dasac_bn_param_grads")
+    return dg, db, dcb
+
+
+def channel_sums(x):
+    lib = L.load()
+    L.require_gpu(x)
+    x = _c(x)
+    N, Cn = x.shape[0], x.shape[1]
+    out = _f32((Cn,), x)
+    L.check(lib.dasac_channel_sums(x.data_ptr(), N, Cn, x[0, 0].numel(), out.data_ptr(), L.stream_ptr()), "dasac_channel_sums")
+    return out
+
+
+def pool_out(n, k, s, p, ceil_mode):
+    """torch's pooling output-size rule."""
+    num = n + 2 * p - k
+    o = (-(-num // s) if ceil_mode else num // s) + 1
+    if ceil_mode and (o - 1) * s >= n + p:
+        o -= 1
+    return o
+
+
+def maxpool_fwd(x, k, s, p, ceil_mode):
+    lib = L.load()
+    L.require_gpu(x)
+    x = _c(x)
+    B, Cn, H, W = x.shape
+    OH, OW = pool_out(H, k, s, p, ceil_mode), pool_out(W, k, s, p, ceil_mode)
+    y = _f32((B, Cn, OH, OW), x)
+    arg = torch.empty((B, Cn, OH, OW), dtype=torch.uint8, device=x.device)
+    L.check(lib.dasac_maxpool_fwd(x.data_ptr(), B * Cn, H, W, OH, OW, k, s, p, y.data_ptr(), arg.data_ptr(), L.stream_ptr()),
+            "dasac_maxpool_fwd")
+    return y, arg
+
+
+def maxpool_bwd(dy, y, arg, in_hw, k, s, p, relu_mask):
+    lib = L.load()
+    L.require_gpu(dy, y, arg)
+    dy = _c(dy)
+    B, Cn, OH, OW = dy.shape
+    H, W = in_hw
+    dx = _f32((B, Cn, H, W), dy)
+    L.check(lib.dasac_maxpool_bwd(dy.data_ptr(), y.data_ptr(), arg.data_ptr(), B * Cn, H, W, OH, OW, k, s, p, int(relu_mask),
+                                  dx.data_ptr(), L.stream_ptr()), "dasac_maxpool_bwd")
+    return dx
+
+
+def add(a, b, out=None):
+    lib = L.load()
+    L.require_gpu(a, b)
+    out = torch.empty_like(a) if out is None else out
+    L.check(lib.dasac_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), L.stream_ptr()), "dasac_add")
+    return out
+
+
+def scale_planes(x, plane_scale):
+    lib = L.load()
+    L.require_gpu(x, plane_scale)
+    x = _c(x)
+    out = torch.empty_like(x)
+    L.check(lib.dasac_scale_planes(x.data_ptr(), _c(plane_scale).data_ptr(), x.shape[0] * x.shape[1], x[0, 0].numel(),
+                                   out.data_ptr(), L.stream_ptr()), "dasac_scale_planes")
+    return out
+
+
+class EmaPlan:
+    """Device-side pointer/chunk tables for the multi-tensor teacher update (built once; rebuilt by the
+    caller when parameter storage moves)."""
+
+    def __init__(self, fast_tensors, slow_tensors):
+        import numpy as np
+        lib = L.load()
+        L.require_gpu(*fast_tensors)
+        L.require_gpu(*slow_tensors)
+        chunk = lib.dasac_ema_chunk_elems()
+        pairs = np.zeros((len(fast_tensors), 3), dtype=np.int64)
+        chunks = []
+        for i, (f, s) in enumerate(zip(fast_tensors, slow_tensors)):
+            assert f.is_contiguous() and s.is_contiguous() and f.numel() == s.numel() and f.dtype == torch.float32
+            pairs[i] = (f.data_ptr(), s.data_ptr(), f.numel())
+            chunks += [(i, j) for j in range((f.numel() + chunk - 1) // chunk)]
+        dev = fast_tensors[0].device
+        self.key = tuple(int(v) for v in pairs[:, :2].reshape(-1))
+        self.pairs = torch.from_numpy(pairs).to(dev)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        self.sq = torch.empty(len(fast_tensors), dtype=torch.float64, device=dev)
+        self.n_tensors, self.n_chunks = len(fast_tensors), len(chunks)
+
+    def run(self, momentum, update):
+        lib = L.load()
+        out = torch.empty(1, dtype=torch.float32, device=self.pairs.device)
+        L.check(lib.dasac_ema_update(self.pairs.data_ptr(), self.n_tensors, self.chunks.data_ptr(), self.n_chunks,
+                                     float(momentum), int(bool(update)), self.sq.data_ptr(), out.data_ptr(), L.stream_ptr()),
+                "dasac_ema_update")
+        return out

@@ -92,6 +92,82 @@ int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M
                             const float* w, const float* scale, float* dw, float* dot,
                             int Cin, int taps, int tap0, dasac_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SAC head (models/sac.py) -- HBM-bound streaming kernels over [B,C,H,W] fp32, C <= 32.
+ *
+ * dasac_upsample_softmax  F.interpolate(bilinear, align_corners=True) of logits [B,C,h,w]
+ *     (deeplabv2.py:217, sac.py:275); optional outputs: `up` (upsampled logits), `probs` =
+ *     softmax zeroed where ignore != 0 (sac.py:276,282), `class_sums[C]` (double) = sum over
+ *     batch and pixels of the unmasked softmax (sac.py:108).
+ * dasac_upsample_bwd      transpose of the upsampling: grad_low = gscale[0] * U^T grad_up
+ *     (gscale: device scalar or NULL), planes = B*C.
+ * dasac_ce_loss           mode 0: mean over ALL pixels of CE(ignore 255) (deeplabv2.py:223-224,
+ *     sac.py:119-132); mode 1: focal_ce_conf with its [B,B,H,W] broadcast (sac.py:134-149):
+ *     loss = sum_hw (sum_i conf_i)(sum_j ce_j)/(B*B*HW).  class_weight [C] or NULL.  dlogits
+ *     (optional) receives d loss / d logits; per_class (optional) [C] as sac.py:138-145.
+ * dasac_warp_affine       grid_sample(x, affine_grid(theta), bilinear, zeros, align_corners=False)
+ * dasac_warp_pool         sac.py:289-305 with _avg_pool (mode 0, :238-269) or _minentropy_pool
+ *     (mode 1, :218-236): probs [N*T,C,H,W] -> pooled [N,C,H,W], mask [N,H,W]; `aligned`
+ *     (optional) = teacher_aligned diagnostic [N*T,C,H,W].
+ * dasac_warp_back         sac.py:309-311: refined[b] = warp(pooled[b/views_per_group]) * warp(mask)
+ * dasac_class_state       sac.py:104-117 running prior update (if update) and the derived
+ *     vectors disc = 1-exp(-chi/beta) (:152), focal = (1-max(chi,0))^p (:120); any may be NULL.
+ */
+int dasac_upsample_softmax(const float* logits, int B, int C, int h, int w, int H, int W,
+                           const uint8_t* ignore, float* up, float* probs, double* class_sums,
+                           dasac_stream_t stream);
+size_t dasac_upsample_bwd_workspace(int planes, int H, int w);
+int dasac_upsample_bwd(const float* grad_up, int planes, int h, int w, int H, int W,
+                       const float* gscale, float* grad_low, void* workspace, size_t ws_bytes,
+                       dasac_stream_t stream);
+size_t dasac_ce_loss_workspace(int B, int C, int64_t HW);
+int dasac_ce_loss(const float* logits, const int64_t* labels, const float* class_weight,
+                  const float* conf, int B, int C, int64_t HW, int mode, float* loss,
+                  float* dlogits, float* per_class, void* workspace, size_t ws_bytes,
+                  dasac_stream_t stream);
+int dasac_warp_affine(const float* x, const float* theta, int B, int C, int H, int W, float* out,
+                      dasac_stream_t stream);
+int dasac_warp_pool(const float* probs, const float* theta, const float* theta_inv, int N, int T,
+                    int C, int H, int W, int mode, float tolerance, float* aligned, float* pooled,
+                    float* mask, dasac_stream_t stream);
+int dasac_warp_back(const float* pooled, const float* mask, const float* theta_inv, int B,
+                    int views_per_group, int C, int H, int W, float* refined,
+                    dasac_stream_t stream);
+int dasac_class_state(float* running_conf, const double* class_sums, int B, int64_t HW, int C,
+                      float beta, float stat_momentum, int update, float focal_p, float* disc,
+                      float* focal, dasac_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Around the convolutions.
+ * dasac_bn_fold          frozen BatchNorm (models/__init__.py:29, basenet.py:97-100) as per-channel
+ *     scale/shift for the conv epilogue: scale = gamma/sqrt(var+eps), shift = beta-(mean-b)*scale.
+ * dasac_bn_param_grads   gamma/beta (and conv-bias) gradients of the folded form from
+ *     dot[c] = sum dz*conv(x) (dasac_conv_wgrad_finish) and sum_dz[c] (dasac_channel_sums).
+ * dasac_maxpool_fwd/bwd  nn.MaxPool2d (deeplabv2.py:126 ceil_mode 3x3/2; VGG 2x2/2); caller passes
+ *     the resolved OH/OW.  bwd with relu_mask folds the ReLU backward of the producer.
+ * dasac_ema_update       momentum teacher (sac.py:83-102) over all tensors in one launch:
+ *     out[0] = sum_t ||slow_t - fast_t||_2 (before the update); slow = slow*m + fast*(1-m).
+ * dasac_scale_planes     Dropout2d with an explicit per-(n,c) keep mask (fcn.py:52,56).
+ */
+int dasac_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                  const float* conv_bias, float eps, int C, float* scale, float* shift,
+                  float* invstd, dasac_stream_t stream);
+int dasac_bn_param_grads(const float* dot, const float* sum_dz, const float* mean,
+                         const float* invstd, const float* scale, const float* conv_bias, int C,
+                         float* dgamma, float* dbeta, float* dbias, dasac_stream_t stream);
+int dasac_channel_sums(const float* x, int N, int C, int64_t HW, float* out, dasac_stream_t stream);
+int dasac_maxpool_fwd(const float* x, int planes, int H, int W, int OH, int OW, int k, int s,
+                      int pad, float* y, uint8_t* argmax, dasac_stream_t stream);
+int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t* argmax, int planes, int H,
+                      int W, int OH, int OW, int k, int s, int pad, int relu_mask, float* dx,
+                      dasac_stream_t stream);
+int dasac_ema_chunk_elems(void);
+int dasac_ema_update(const void* pairs, int n_tensors, const int32_t* chunks, int n_chunks,
+                     float momentum, int update, double* sq, float* out, dasac_stream_t stream);
+int dasac_scale_planes(const float* x, const float* plane_scale, int64_t planes, int64_t HW,
+                       float* y, dasac_stream_t stream);
+int dasac_add(const float* a, const float* b, float* out, int64_t n, dasac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,165 @@
+"""SAC head kernels vs the CPU oracle and the reference-captured goldens, through the C ABI.
+Float tolerance: 1e-3 relative to the tensor max (north_star); measured errors are ~1e-6."""
+import pytest
+import torch
+
+from oracle import head_ref as H
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+TOL = 1e-5
+
+
+def test_upsample_softmax_golden_g3(golden):
+    from dasac_hip import ops
+    g = golden("g3_bilinear")
+    up, _, _ = ops.upsample_softmax(T(g["x"]).cuda(), (65, 97))
+    assert rel_err(up, g["y"]) < TOL
+    up, _, _ = ops.upsample_softmax(T(g["row"]).cuda(), (769, 9))
+    assert rel_err(up, g["yrow"]) < TOL
+    up, _, _ = ops.upsample_softmax(T(g["x2"]).cuda(), (8, 12))
+    assert rel_err(up, g["y2"]) < TOL
+
+
+def test_upsample_softmax_probs_and_sums():
+    from dasac_hip import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 19, 9, 13, generator=g) * 3
+    ign = torch.rand(3, 65, 97, generator=g) < 0.2
+    up, probs, sums = ops.upsample_softmax(x.cuda(), (65, 97), ign.cuda(), want_probs=True, want_sums=True)
+    ru = H.upsample_bilinear_ac(x, 65, 97)
+    rp = torch.softmax(ru, 1)
+    assert rel_err(up, ru) < TOL
+    assert rel_err(sums, rp.double().sum((0, 2, 3))) < TOL
+    assert rel_err(probs, rp * (~ign)[:, None]) < TOL
+    assert float(probs.cpu()[ign[:, None].expand_as(rp)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 9, 13, 65, 97), (1, 3, 4, 6, 8, 12), (2, 19, 5, 5, 33, 33), (1, 2, 1, 7, 1, 49)])
+def test_upsample_backward_is_the_transpose(shape):
+    from dasac_hip import ops
+    B, C, h, w, Hh, W = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, h, w, generator=g, requires_grad=True)
+    gu = torch.randn(B, C, Hh, W, generator=g)
+    H.upsample_bilinear_ac(x, Hh, W).backward(gu)
+    gs = torch.tensor([0.37])
+    d = ops.upsample_bwd(gu.cuda(), (h, w), gs.cuda())
+    assert rel_err(d, 0.37 * x.grad) < TOL
+
+
+def test_ce_losses_golden_g6(golden):
+    from dasac_hip import ops
+    g = golden("g6_losses")
+    x, y, conf, chi = T(g["logits"]).cuda(), T(g["y"]).cuda(), T(g["conf"]).cuda(), T(g["chi"])
+    fw = H.focal_weight(chi, 3).cuda()
+    loss, dl, pc = ops.ce_loss(x, y, fw, conf, want_grad=True, want_per_class=True)
+    assert rel_err(loss, g["conf_loss"]) < TOL and rel_err(dl, g["conf_grad"]) < TOL
+    assert rel_err(pc, g["conf_per_class"]) < TOL
+    loss, dl, pc = ops.ce_loss(x, y, fw, None, want_grad=True, want_per_class=True)
+    assert rel_err(loss, g["plain_loss"]) < TOL and rel_err(dl, g["plain_grad"]) < TOL
+    assert rel_err(pc, g["plain_per_class"]) < TOL
+    loss, dl, _ = ops.ce_loss(x, y, None, None, want_grad=True)
+    assert rel_err(loss, g["ce_loss"]) < TOL and rel_err(dl, g["ce_grad"]) < TOL
+
+
+def test_ce_all_ignored_and_batch_of_one():
+    from dasac_hip import ops
+    x = torch.randn(1, 19, 5, 7)
+    y = torch.full((1, 5, 7), 255, dtype=torch.int64)
+    loss, dl, _ = ops.ce_loss(x.cuda(), y.cuda(), want_grad=True)
+    assert float(loss) == 0.0 and float(dl.abs().max()) == 0.0
+
+
+def test_warp_affine_golden_g4(golden):
+    from dasac_hip import ops
+    g = golden("g4_refine")
+    out = ops.warp_affine(T(g["frames"]).cuda(), T(g["affine"]).cuda())
+    assert rel_err(out, g["warp_frames"]) < TOL
+    assert rel_err(out, g["avg_pool_frames_aligned"]) < TOL
+
+
+def _refine_on_gpu(g, mode):
+    from dasac_hip import ops
+    frames, logits = T(g["frames"]).cuda(), T(g["logits"]).cuda()
+    aff, inv, ign = T(g["affine"]).cuda(), T(g["affine_inv"]).cuda(), T(g["ignore"]).cuda()
+    Tn = int(g["T"])
+    chi = T(g["chi_in"]).clone().cuda()
+    B, _, Hh, W = frames.shape
+    _, probs, sums = ops.upsample_softmax(logits, (Hh, W), ign, want_up=False, want_probs=True, want_sums=True)
+    ops.class_state(chi, sums, B, Hh * W, 1e-3, 0.99, True, 3.0)
+    pooled, mask, aligned = ops.warp_pool(probs, aff, inv, Tn, mode)
+    refined = ops.warp_back(pooled, mask, inv, Tn)
+    return refined, chi, aligned
+
+
+def test_refine_avg_pool_golden_g4(golden):
+    g = golden("g4_refine")
+    refined, chi, aligned = _refine_on_gpu(g, "avg_pool")
+    assert rel_err(refined, g["avg_pool_refined"]) < 2e-5
+    assert rel_err(chi, g["avg_pool_chi_out"]) < 1e-6
+    assert rel_err(aligned, g["avg_pool_teacher_aligned"]) < TOL
+
+
+def test_refine_minentropy_pool_golden_g4(golden):
+    g = golden("g4_refine")
+    refined, chi, _ = _refine_on_gpu(g, "minentropy_pool")
+    ref = T(g["minentropy_pool_refined"])
+    bad = ((refined.cpu() - ref).abs().amax(1) > 1e-4).float().mean()
+    assert bad < 2e-3                       # argmin over views is a discontinuity
+    assert rel_err(chi, g["minentropy_pool_chi_out"]) < 1e-6
+
+
+def test_class_state_sequence_golden_g7(golden):
+    from dasac_hip import ops
+    g = golden("g7_state")
+    chi = torch.zeros(19, device="cuda")
+    for it in range(4):
+        if it == 1:
+            chi.fill_(1e-3)
+        p = T(g["probs"][it]).cuda()
+        sums = p.double().sum((0, 2, 3))
+        disc, focal = ops.class_state(chi, sums, p.shape[0], p.shape[2] * p.shape[3], 1e-3, 0.99, True, 3.0)
+        assert rel_err(chi, g["chi_seq"][it]) < 1e-6
+        assert rel_err(disc, H.threshold_discount(chi.cpu(), 1e-3)) < 1e-6
+        assert rel_err(focal, H.focal_weight(chi.cpu(), 3)) < 1e-6
+
+
+def test_maxpool_and_relu_masked_backward():
+    from dasac_hip import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    for (k, s, p, ceil, Hh, W) in ((3, 2, 1, True, 33, 41), (2, 2, 0, False, 16, 24), (3, 2, 1, True, 32, 32)):
+        x = F.relu(torch.randn(2, 5, Hh, W, generator=g)).requires_grad_(True)
+        y = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        yy, arg = ops.maxpool_fwd(x.detach().cuda(), k, s, p, ceil)
+        assert torch.equal(yy.cpu(), y.detach())
+        dx = ops.maxpool_bwd(dy.cuda(), yy, arg, (Hh, W), k, s, p, relu_mask=True)
+        # oracle: maxpool backward followed by the ReLU backward of the producer (grad * (x>0))
+        ref = x.grad * (x.detach() > 0)
+        assert rel_err(dx, ref) < TOL
+
+
+def test_bn_fold_channel_sums_ema():
+    from dasac_hip import ops
+    g = torch.Generator().manual_seed(4)
+    gam, bet, mu, var = torch.rand(37, generator=g) + 0.5, torch.randn(37, generator=g), torch.randn(37, generator=g), torch.rand(37, generator=g) + 0.5
+    sc, sh, inv = ops.bn_fold(gam.cuda(), bet.cuda(), mu.cuda(), var.cuda(), 1e-5)
+    x = torch.randn(2, 37, 5, 6, generator=g)
+    ref = torch.nn.functional.batch_norm(x, mu, var, gam, bet, False, 0.1, 1e-5)
+    assert rel_err(x * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1), ref) < 1e-6
+    assert rel_err(ops.channel_sums(x.cuda()), x.sum((0, 2, 3))) < 1e-6
+    fast = [torch.randn(n, generator=g) for n in (5, 4097, 70000)]
+    slow = [torch.randn(n, generator=g) for n in (5, 4097, 70000)]
+    fd, sd = [t.cuda() for t in fast], [t.cuda() for t in slow]
+    plan = ops.EmaPlan(fd, sd)
+    for upd in (False, True, False):
+        ref = H.momentum_update({"a.weight": slow[0], "b.bias": slow[1], "c.running_var": slow[2]},
+                                {"a.weight": fast[0], "b.bias": fast[1], "c.running_var": fast[2]}, 0.99, upd)
+        out = plan.run(0.99, upd)
+        assert rel_err(out, ref) < 1e-6
+        for a, b in zip(sd, slow):
+            assert rel_err(a, b) < 1e-6
