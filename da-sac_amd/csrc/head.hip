@@ -171,14 +171,15 @@ __global__ __launch_bounds__(kHB) void upsample_bwd_y(const float* __restrict__ 
 // per_class (optional, [C] double): sum over pixels of ce scattered by label (ignored -> class 0, value 0).
 __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, const int64_t* __restrict__ y,
                                                const float* __restrict__ cw, const float* __restrict__ conf, int B, int C,
-                                               int HW, int mode, float* __restrict__ dx, double* __restrict__ partial,
-                                               double* __restrict__ per_class) {
+                                               int HW, int mode, const float* __restrict__ gscale, float* __restrict__ dx,
+                                               double* __restrict__ partial, double* __restrict__ per_class) {
   double lsum = 0.0;
   __shared__ float s_pc[kMaxC];
   if (per_class) {
     if (threadIdx.x < kMaxC) s_pc[threadIdx.x] = 0.f;
     __syncthreads();
   }
+  const float gs = gscale ? gscale[0] : 1.f;   // upstream gradient of the scalar loss (device side)
   const float norm = mode == 1 ? 1.f / ((float)B * (float)B * (float)HW) : 1.f / ((float)B * (float)HW);
   for (int p = blockIdx.x * kHB + threadIdx.x; p < HW; p += gridDim.x * kHB) {
     float cs = 1.f;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, cons
       for (int b = 0; b < B; ++b) cs += conf[(size_t)b * HW + p];
     }
     const float pw = cs * norm;
+    const float gpw = pw * gs;
     float cesum = 0.f;
     for (int b = 0; b < B; ++b) {
       const size_t base = (size_t)b * C * HW + p;
@@ -214,10 +216,10 @@ __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, cons
       cesum += ce;
       if (per_class && valid && ce != 0.f) atomicAdd(&s_pc[lab], ce);
       if (dx) {
-        const float k = pw * wgt / den;
+        const float k = gpw * wgt / den;
 #pragma unroll
         for (int c = 0; c < kMaxC; ++c)
-          if (c < C) dx[base + (size_t)c * HW] = k * v[c] - ((c == lab) ? pw * wgt : 0.f);
+          if (c < C) dx[base + (size_t)c * HW] = k * v[c] - ((c == lab) ? gpw * wgt : 0.f);
       }
     }
     lsum += (double)pw * (double)cesum;
@@ -451,8 +453,8 @@ extern "C" size_t dasac_ce_loss_workspace(int B, int C, int64_t HW) {
 }
 
 extern "C" int dasac_ce_loss(const float* logits, const int64_t* labels, const float* class_weight, const float* conf,
-                             int B, int C, int64_t HW, int mode, float* loss, float* dlogits, float* per_class,
-                             void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+                             int B, int C, int64_t HW, int mode, const float* gscale, float* loss, float* dlogits,
+                             float* per_class, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
   DASAC_REQUIRE(logits && labels && loss && workspace, "ce_loss: null pointer");
   DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && HW > 0 && HW < (1ll << 31) && (mode == 0 || (mode == 1 && conf)), "ce_loss: bad arguments");
   if (ws_bytes < dasac_ce_loss_workspace(B, C, HW)) return fail(DASAC_EWORKSPACE, "ce_loss: workspace too small");
@@ -461,8 +463,8 @@ extern "C" int dasac_ce_loss(const float* logits, const int64_t* labels, const f
   double* partial = reinterpret_cast<double*>(workspace);
   double* pc = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)blocks * sizeof(double), 256));
   if (per_class) DASAC_HIP(hipMemsetAsync(pc, 0, kMaxC * sizeof(double), s));
-  hipLaunchKernelGGL(ce_loss, dim3(blocks), dim3(kHB), 0, s, logits, labels, class_weight, conf, B, C, (int)HW, mode, dlogits,
-                     partial, per_class ? pc : nullptr);
+  hipLaunchKernelGGL(ce_loss, dim3(blocks), dim3(kHB), 0, s, logits, labels, class_weight, conf, B, C, (int)HW, mode, gscale,
+                     dlogits, partial, per_class ? pc : nullptr);
   DASAC_CHECK_LAUNCH("ce_loss");
   hipLaunchKernelGGL(ce_finish, dim3(1), dim3(64), 0, s, partial, blocks, loss, pc, per_class, C, 1.0 / ((double)HW * B));
   DASAC_CHECK_LAUNCH("ce_finish");

@@ -168,6 +168,11 @@ __global__ __launch_bounds__(256) void add2(const float* __restrict__ a, const f
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] + b[i];
 }
 
+__global__ __launch_bounds__(256) void relu_mask(const float* __restrict__ dy, const float* __restrict__ y,
+                                                 float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
 }  // namespace dasac
 
 using namespace dasac;
@@ -251,5 +256,12 @@ extern "C" int dasac_add(const float* a, const float* b, float* out, int64_t n, 
   DASAC_REQUIRE(a && b && out && n > 0, "add: bad arguments");
   hipLaunchKernelGGL(add2, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), a, b, out, n);
   DASAC_CHECK_LAUNCH("add");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_relu_mask(const float* dy, const float* y, float* out, int64_t n, dasac_stream_t stream) {
+  DASAC_REQUIRE(dy && y && out && n > 0, "relu_mask: bad arguments");
+  hipLaunchKernelGGL(relu_mask, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), dy, y, out, n);
+  DASAC_CHECK_LAUNCH("relu_mask");
   return DASAC_OK;
 }

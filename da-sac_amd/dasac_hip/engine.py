@@ -1,0 +1,402 @@
+"""Fused forward/backward executor for the segmentation backbones.
+
+A network (`models.deeplabv2`, `models.fcn`) describes itself once as a flat *plan* of fused ops
+over numbered activation slots; this module runs the plan forward and -- hand-written, no autograd
+tape inside the backbone -- backward, calling only the C-ABI kernels of libdasac_hip.so:
+
+  ConvOp   implicit-GEMM convolution with the frozen-BN scale/shift (or bias), residual add and ReLU
+           in the epilogue ("ABN": conv+BN+ReLU fused).  Several branches (ASPP) are one contraction.
+           Backward: channel sums (d beta), split-K weight-gradient GEMM (+ the d gamma dot term),
+           data-gradient GEMM whose epilogue accumulates into the producer's gradient and applies the
+           producer's ReLU mask -- so no stand-alone elementwise pass exists in the backbone.
+  PoolOp   max pooling with the ReLU backward of its producer folded into the gradient routing.
+  Up2AddOp FCN-8s skip fusion: up_x2(a) + b.          ScaleOp: Dropout2d with an explicit mask.
+
+The whole plan is exposed to PyTorch as ONE autograd.Function (inputs: image + all parameters), so
+DistributedDataParallel sees ordinary parameter gradients.
+"""
+import torch
+
+from . import ops
+from . import lib as L
+
+
+class ConvOp:
+    kind = "conv"
+
+    def __init__(self, src, dst, convs, bn, relu, res):
+        c0 = convs[0]
+        self.src, self.dst, self.res, self.relu = src, dst, res, bool(relu)
+        self.convs, self.bn = list(convs), bn
+        assert all(c.stride == c0.stride and c.in_channels == c0.in_channels and c.out_channels == c0.out_channels
+                   and c.groups == 1 for c in convs)
+        assert c0.stride[0] == c0.stride[1]
+        branches = []
+        for c in convs:
+            assert c.dilation[0] == c.dilation[1] and c.padding[0] == c.padding[1]
+            branches.append((c.kernel_size[0], c.kernel_size[1], c.dilation[0], c.padding[0]))
+        self.spec = ops.ConvSpec(c0.in_channels, c0.out_channels, branches, c0.stride[0])
+        self.has_bias = c0.bias is not None
+        assert bn is None or len(convs) == 1
+
+    def params(self):
+        out = [c.weight for c in self.convs]
+        if self.has_bias:
+            out += [c.bias for c in self.convs]
+        if self.bn is not None:
+            out += [self.bn.weight, self.bn.bias]
+        return out
+
+
+class PoolOp:
+    kind = "pool"
+
+    def __init__(self, src, dst, k, s, p, ceil_mode):
+        self.src, self.dst, self.k, self.s, self.p, self.ceil = src, dst, k, s, p, bool(ceil_mode)
+
+    def params(self):
+        return []
+
+
+class Up2AddOp:
+    kind = "up2add"
+
+    def __init__(self, src, skip, dst):
+        self.src, self.skip, self.dst = src, skip, dst
+
+    def params(self):
+        return []
+
+
+class ScaleOp:
+    """Dropout2d(p) in train mode: y = x * keep/(1-p) per (n, c) plane."""
+    kind = "drop"
+
+    def __init__(self, src, dst, module):
+        self.src, self.dst, self.module = src, dst, module
+
+    def params(self):
+        return []
+
+
+class Plan:
+    """Builder used by the model classes."""
+
+    def __init__(self):
+        self.ops, self.n_slots, self.output = [], 1, None     # slot 0 = input image
+
+    def _new(self):
+        self.n_slots += 1
+        return self.n_slots - 1
+
+    def conv(self, src, conv, bn=None, relu=False, res=None):
+        dst = self._new()
+        self.ops.append(ConvOp(src, dst, [conv], bn, relu, res))
+        return dst
+
+    def conv_sum(self, src, convs):
+        dst = self._new()
+        self.ops.append(ConvOp(src, dst, list(convs), None, False, None))
+        return dst
+
+    def maxpool(self, src, k, s, p=0, ceil_mode=False):
+        dst = self._new()
+        self.ops.append(PoolOp(src, dst, k, s, p, ceil_mode))
+        return dst
+
+    def up2_add(self, src, skip):
+        dst = self._new()
+        self.ops.append(Up2AddOp(src, skip, dst))
+        return dst
+
+    def dropout2d(self, src, module):
+        dst = self._new()
+        self.ops.append(ScaleOp(src, dst, module))
+        return dst
+
+    def finish(self, output):
+        self.output = output
+        return self
+
+
+def _ver(t):
+    return (t.data_ptr(), t._version)
+
+
+class Engine:
+    """Executes a Plan.  Keeps per-layer caches of gather tables (by spatial size) and of packed
+    weights / folded BN vectors (invalidated by the parameters' version counters)."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.params = []
+        for op in plan.ops:
+            op.pidx = []
+            for p in op.params():
+                op.pidx.append(len(self.params))
+                self.params.append(p)
+        self.consumers = [0] * plan.n_slots
+        self.producer = [None] * plan.n_slots
+        for i, op in enumerate(plan.ops):
+            self.producer[op.dst] = op
+            for s in self._inputs(op):
+                self.consumers[s] += 1
+        self.last_use = [0] * plan.n_slots
+        for i, op in enumerate(plan.ops):
+            for s in self._inputs(op):
+                self.last_use[s] = i
+        self.last_use[plan.output] = len(plan.ops)
+        self._tables, self._packs, self._folds = {}, {}, {}
+
+    @staticmethod
+    def _inputs(op):
+        if op.kind == "conv":
+            return [op.src] + ([op.res] if op.res is not None else [])
+        if op.kind == "up2add":
+            return [op.src, op.skip]
+        return [op.src]
+
+    # ---------------------------------------------------------------- caches
+    def table(self, op, h, w, transposed, device):
+        key = (id(op), h, w, transposed, device.index)
+        t = self._tables.get(key)
+        if t is None:
+            t = ops.conv_table(op.spec, h, w, transposed, device)
+            self._tables[key] = t
+        return t
+
+    def fold(self, op):
+        """(scale, shift, invstd) of the frozen BN (plus conv bias), or (None, bias_sum, None)."""
+        if op.bn is None:
+            if not op.has_bias:
+                return None, None, None
+            if len(op.convs) == 1:
+                return None, op.convs[0].bias.detach(), None
+            key = ("bsum", id(op)) + tuple(_ver(c.bias) for c in op.convs)
+            ent = self._folds.get(id(op))
+            if ent is None or ent[0] != key:
+                acc = op.convs[0].bias.detach()
+                for c in op.convs[1:]:
+                    acc = ops.add(acc, c.bias.detach())
+                ent = (key, (None, acc, None))
+                self._folds[id(op)] = ent
+            return ent[1]
+        bn, cb = op.bn, (op.convs[0].bias if op.has_bias else None)
+        key = (_ver(bn.weight), _ver(bn.bias), _ver(bn.running_mean), _ver(bn.running_var), None if cb is None else _ver(cb))
+        ent = self._folds.get(id(op))
+        if ent is None or ent[0] != key:
+            ent = (key, ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps,
+                                    None if cb is None else cb.detach()))
+            self._folds[id(op)] = ent
+        return ent[1]
+
+    def packed(self, op, transposed, scale=None):
+        key = tuple(_ver(c.weight) for c in op.convs) + ((_ver(scale),) if scale is not None else ())
+        slot = (id(op), transposed)
+        ent = self._packs.get(slot)
+        if ent is None or ent[0] != key:
+            buf = None if ent is None else ent[1]
+            buf = ops.conv_pack(op.spec, [c.weight.detach() for c in op.convs], transposed, scale, out=buf)
+            ent = (key, buf, scale)      # keep `scale` alive: its data_ptr is part of the key
+            self._packs[slot] = ent
+        return ent[1]
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, x, keep):
+        """Runs the plan.  keep=True retains what backward needs; returns (output, saved)."""
+        L.require_gpu(x)
+        acts = {0: x}
+        saved = {"acts": acts, "aux": {}}
+        for i, op in enumerate(self.plan.ops):
+            xin = acts[op.src]
+            if op.kind == "conv":
+                Nb, _, H, W = xin.shape
+                OH, OW = op.spec.out_hw(H, W)
+                scale, shift, _ = self.fold(op)
+                out = torch.empty((Nb, op.spec.cout, OH, OW), dtype=torch.float32, device=xin.device)
+                ops.conv_gemm(xin, self.packed(op, False), self.table(op, H, W, False, xin.device), out, (OH, OW),
+                              op.spec.stride, op.spec.cout, op.spec.K, 1, scale, shift,
+                              None if op.res is None else acts[op.res], None, op.relu)
+            elif op.kind == "pool":
+                out, arg = ops.maxpool_fwd(xin, op.k, op.s, op.p, op.ceil)
+                if keep:
+                    saved["aux"][i] = arg
+            elif op.kind == "up2add":
+                up, _, _ = ops.upsample_softmax(xin, (2 * xin.shape[2], 2 * xin.shape[3]))
+                out = ops.add(up, acts[op.skip], out=up)
+            elif op.kind == "drop":
+                m = op.module
+                if m.training and m.p > 0:
+                    keep_mask = (torch.rand(xin.shape[:2], device=xin.device) >= m.p).to(torch.float32) / (1.0 - m.p)
+                    out = ops.scale_planes(xin, keep_mask)
+                    if keep:
+                        saved["aux"][i] = keep_mask
+                else:
+                    out = xin
+            else:
+                raise AssertionError(op.kind)
+            acts[op.dst] = out
+            if not keep:
+                for s in self._inputs(op):
+                    if self.last_use[s] == i and s != 0:
+                        del acts[s]
+        return acts[self.plan.output], saved
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, saved, grad_out, need):
+        """grad_out: gradient w.r.t. the plan output.  need[i]: whether parameter i wants a gradient.
+        Returns the list of parameter gradients (None where not needed)."""
+        acts, aux = saved["acts"], saved["aux"]
+        grads = [None] * len(self.params)
+        g = {self.plan.output: grad_out.contiguous()}
+        pending = list(self.consumers)
+        pending[self.plan.output] = 0
+
+        def relu_producer(slot):
+            p = self.producer[slot]
+            return p is not None and p.kind == "conv" and p.relu
+
+        def join_identity(slot, t):
+            """A pass-through consumer (residual / skip) hands its gradient to `slot`."""
+            pending[slot] -= 1
+            cur = g.get(slot)
+            t = t if cur is None else ops.add(cur, t)
+            if pending[slot] == 0 and relu_producer(slot):
+                t = ops.relu_mask(t, acts[slot])
+            g[slot] = t
+
+        for i in range(len(self.plan.ops) - 1, -1, -1):
+            op = self.plan.ops[i]
+            dz = g.pop(op.dst, None)
+            if dz is None:
+                continue
+            assert pending[op.dst] == 0
+            xin = acts[op.src]
+            if op.kind == "conv":
+                spec = op.spec
+                Nb, _, H, W = xin.shape
+                scale, shift, invstd = self.fold(op)
+                nw = len(op.convs)
+                w_need = [need[j] for j in op.pidx[:nw]]
+                rest = op.pidx[nw:]
+                b_idx = rest[:nw] if op.has_bias else []
+                bn_idx = rest[len(b_idx):]
+                want_bn = op.bn is not None and any(need[j] for j in bn_idx)
+                want_bias = any(need[j] for j in b_idx)
+                sums = ops.channel_sums(dz) if (want_bn or want_bias) else None
+                dot = None
+                if any(w_need) or want_bn:
+                    if want_bn:
+                        dot = torch.zeros(spec.cout, dtype=torch.float32, device=dz.device)
+                    dws = ops.conv_wgrad(spec, dz, xin, [c.weight.detach() for c in op.convs], scale=scale, dot=dot,
+                                         table=self.table(op, H, W, False, xin.device))
+                    for j, dw in zip(op.pidx[:nw], dws):
+                        if need[j]:
+                            grads[j] = dw
+                if op.bn is not None:
+                    cb = op.convs[0].bias.detach() if op.has_bias else None
+                    dg, db, dcb = ops.bn_param_grads(dot, sums, op.bn.running_mean, invstd, scale, cb,
+                                                     want_gamma=want_bn, want_beta=want_bn, want_bias=want_bias) \
+                        if (want_bn or want_bias) else (None, None, None)
+                    if want_bn:
+                        grads[bn_idx[0]], grads[bn_idx[1]] = dg, db
+                    if want_bias:
+                        grads[b_idx[0]] = dcb
+                elif want_bias:
+                    for n_, j in enumerate(b_idx):        # every branch bias sees the same gradient
+                        if need[j]:
+                            grads[j] = sums if n_ == 0 else sums.clone()
+                if op.src != 0:
+                    pending[op.src] -= 1
+                    last = pending[op.src] == 0
+                    mask = acts[op.src] if (last and relu_producer(op.src)) else None
+                    OH, OW = dz.shape[2:]
+                    g[op.src] = ops.conv_dgrad(spec, dz, None, (H, W), scale=scale, res=g.get(op.src), mask=mask,
+                                               table=self.table(op, OH, OW, True, dz.device),
+                                               packed=self.packed(op, True, scale))
+                if op.res is not None:
+                    join_identity(op.res, dz)
+            elif op.kind == "pool":
+                assert self.consumers[op.src] == 1
+                pending[op.src] -= 1
+                g[op.src] = ops.maxpool_bwd(dz, acts[op.dst], aux[i], xin.shape[2:], op.k, op.s, op.p,
+                                            relu_mask=relu_producer(op.src))
+            elif op.kind == "up2add":
+                join_identity(op.skip, dz)
+                join_identity(op.src, ops.upsample_bwd(dz, xin.shape[2:]))
+            elif op.kind == "drop":
+                m = aux.get(i)
+                join_identity(op.src, dz if m is None else ops.scale_planes(dz, m))
+            # the activation of this op's output is no longer needed
+            acts.pop(op.dst, None)
+        return grads
+
+
+class _PlanFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, x, *params):
+        keep = any(p.requires_grad for p in params)
+        out, saved = engine.forward(x, keep)
+        ctx.engine = engine
+        ctx.saved = saved if keep else None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        need = list(ctx.needs_input_grad[2:])
+        grads = ctx.engine.backward(ctx.saved, grad_out, need)
+        ctx.saved = None
+        return (None, None) + tuple(grads)
+
+
+def run_plan(engine, x):
+    """logits = plan(x); differentiable w.r.t. every parameter of the plan."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in engine.params):
+        return _PlanFunction.apply(engine, x, *engine.params)
+    out, _ = engine.forward(x, keep=False)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# head functions with gradients
+# --------------------------------------------------------------------------------------------------
+class _Upsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, size):
+        ctx.low = tuple(logits.shape[2:])
+        up, _, _ = ops.upsample_softmax(logits, size)
+        return up
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.upsample_bwd(g, ctx.low), None
+
+
+def upsample_bilinear(logits, size):
+    """F.interpolate(logits, size, mode='bilinear', align_corners=True) (deeplabv2.py:217)."""
+    return _Upsample.apply(logits, tuple(int(s) for s in size))
+
+
+class _CELoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits_up, labels, class_weight, conf):
+        loss, _, _ = ops.ce_loss(logits_up, labels, class_weight, conf)
+        ctx.save_for_backward(logits_up, labels, class_weight, conf)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits_up, labels, class_weight, conf = ctx.saved_tensors
+        _, dl, _ = ops.ce_loss(logits_up, labels, class_weight, conf, want_grad=True, gscale=g.contiguous())
+        return dl, None, None, None
+
+
+def ce_mean_all_pixels(logits_up, labels):
+    """criterion(logits_up, y).mean().view(1) with CrossEntropyLoss(ignore_index=255, reduction='none')
+    (deeplabv2.py:223-224): the mean runs over ALL pixels, ignored ones included."""
+    return _CELoss.apply(logits_up, labels, None, None)
+
+
+def focal_ce(logits_up, labels, class_weight, conf=None):
+    """sac.py:119-149 loss value ([1]); conf given -> `_focal_ce_conf` broadcast form."""
+    return _CELoss.apply(logits_up, labels, class_weight, conf)

@@ -27,7 +27,7 @@ PROTOTYPES = {
     "dasac_upsample_bwd_workspace": (_sz, [_i, _i, _i]),
     "dasac_upsample_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "dasac_ce_loss_workspace": (_sz, [_i, _i, _l]),
-    "dasac_ce_loss": (_i, [_p, _p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _sz, _p]),
+    "dasac_ce_loss": (_i, [_p, _p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "dasac_warp_affine": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "dasac_warp_pool": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "dasac_warp_back": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
@@ -41,6 +41,7 @@ PROTOTYPES = {
     "dasac_ema_update": (_i, [_p, _i, _p, _i, _f, _i, _p, _p, _p]),
     "dasac_scale_planes": (_i, [_p, _p, _l, _l, _p, _p]),
     "dasac_add": (_i, [_p, _p, _p, _l, _p]),
+    "dasac_relu_mask": (_i, [_p, _p, _p, _l, _p]),
     "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

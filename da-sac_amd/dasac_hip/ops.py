@@ -118,14 +118,16 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
         dx = torch.empty((Nb, spec.cin, H, W), dtype=torch.float32, device=dz.device)
         return conv_gemm(dz, packed, table, dx, (H, W), 1, spec.cin, spec.Kt, 1, None, None, res, mask, False)
     assert spec.taps == 1 and spec.branches[0][3] == 0, "strided data-gradient only for 1x1 convolutions"
-    dx = torch.empty((Nb, spec.cin, H, W), dtype=torch.float32, device=dz.device)
+    # scatter onto the stride lattice.  Positions off the lattice keep `res` (or 0): the accumulation
+    # runs IN PLACE on `res` (each element is read and written by the same thread).
     if res is None:
+        dx = torch.empty((Nb, spec.cin, H, W), dtype=torch.float32, device=dz.device)
         dx.zero_()
     else:
-        dx.copy_(res)
-    # scatter onto the stride lattice; positions off the lattice keep res (or 0)
-    return conv_gemm(dz, packed, table, dx, (OH, OW), 1, spec.cin, spec.Kt, spec.stride, None, None,
-                     dx if res is not None else None, mask, False)
+        dx = res
+    conv_gemm(dz, packed, table, dx, (OH, OW), 1, spec.cin, spec.Kt, spec.stride, None, None,
+              dx if res is not None else None, None, False)
+    return relu_mask(dx, mask) if mask is not None else dx
 
 
 def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None):
@@ -187,7 +189,7 @@ def upsample_bwd(grad_up, low_hw, gscale=None):
     return out
 
 
-def ce_loss(logits_up, labels, class_weight=None, conf=None, want_grad=False, want_per_class=False):
+def ce_loss(logits_up, labels, class_weight=None, conf=None, want_grad=False, want_per_class=False, gscale=None):
     """Returns (loss[1], dlogits or None, per_class or None); conf given -> focal_ce_conf broadcast form."""
     lib = L.load()
     L.require_gpu(logits_up, labels, class_weight, conf)
@@ -200,7 +202,7 @@ def ce_loss(logits_up, labels, class_weight=None, conf=None, want_grad=False, wa
     nbytes = lib.dasac_ce_loss_workspace(B, Cn, HW)
     ws = L.workspace(nbytes, logits_up.device)
     L.check(lib.dasac_ce_loss(logits_up.data_ptr(), labels.data_ptr(), L.ptr(class_weight), L.ptr(None if conf is None else _c(conf)),
-                              B, Cn, HW, 0 if conf is None else 1, loss.data_ptr(), L.ptr(dl), L.ptr(pc), ws.data_ptr(),
+                              B, Cn, HW, 0 if conf is None else 1, L.ptr(gscale), loss.data_ptr(), L.ptr(dl), L.ptr(pc), ws.data_ptr(),
                               ws.numel(), L.stream_ptr()), "dasac_ce_loss")
     return loss, dl, pc
 
@@ -335,6 +337,14 @@ def add(a, b, out=None):
     L.require_gpu(a, b)
     out = torch.empty_like(a) if out is None else out
     L.check(lib.dasac_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), L.stream_ptr()), "dasac_add")
+    return out
+
+
+def relu_mask(dy, y):
+    lib = L.load()
+    L.require_gpu(dy, y)
+    out = torch.empty_like(dy)
+    L.check(lib.dasac_relu_mask(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), L.stream_ptr()), "dasac_relu_mask")
     return out
 
 

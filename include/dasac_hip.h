@@ -104,7 +104,8 @@ int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M
  * dasac_ce_loss           mode 0: mean over ALL pixels of CE(ignore 255) (deeplabv2.py:223-224,
  *     sac.py:119-132); mode 1: focal_ce_conf with its [B,B,H,W] broadcast (sac.py:134-149):
  *     loss = sum_hw (sum_i conf_i)(sum_j ce_j)/(B*B*HW).  class_weight [C] or NULL.  dlogits
- *     (optional) receives d loss / d logits; per_class (optional) [C] as sac.py:138-145.
+ *     (optional) receives gscale[0] * d loss / d logits (gscale: device scalar = upstream
+ *     gradient of the loss, NULL = 1); per_class (optional) [C] as sac.py:138-145.
  * dasac_warp_affine       grid_sample(x, affine_grid(theta), bilinear, zeros, align_corners=False)
  * dasac_warp_pool         sac.py:289-305 with _avg_pool (mode 0, :238-269) or _minentropy_pool
  *     (mode 1, :218-236): probs [N*T,C,H,W] -> pooled [N,C,H,W], mask [N,H,W]; `aligned`
@@ -122,8 +123,8 @@ int dasac_upsample_bwd(const float* grad_up, int planes, int h, int w, int H, in
                        dasac_stream_t stream);
 size_t dasac_ce_loss_workspace(int B, int C, int64_t HW);
 int dasac_ce_loss(const float* logits, const int64_t* labels, const float* class_weight,
-                  const float* conf, int B, int C, int64_t HW, int mode, float* loss,
-                  float* dlogits, float* per_class, void* workspace, size_t ws_bytes,
+                  const float* conf, int B, int C, int64_t HW, int mode, const float* gscale,
+                  float* loss, float* dlogits, float* per_class, void* workspace, size_t ws_bytes,
                   dasac_stream_t stream);
 int dasac_warp_affine(const float* x, const float* theta, int B, int C, int H, int W, float* out,
                       dasac_stream_t stream);
@@ -167,6 +168,8 @@ int dasac_ema_update(const void* pairs, int n_tensors, const int32_t* chunks, in
 int dasac_scale_planes(const float* x, const float* plane_scale, int64_t planes, int64_t HW,
                        float* y, dasac_stream_t stream);
 int dasac_add(const float* a, const float* b, float* out, int64_t n, dasac_stream_t stream);
+/* out = y > 0 ? dy : 0  (ReLU backward, F.relu / nn.ReLU(inplace) of deeplabv2.py:84,88,97) */
+int dasac_relu_mask(const float* dy, const float* y, float* out, int64_t n, dasac_stream_t stream);
 
 #ifdef __cplusplus
 }

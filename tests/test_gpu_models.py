@@ -1,0 +1,151 @@
+"""End-to-end parity of the drop-in `models` package (HIP engine) against vectors captured from the
+reference (tests/golden) and against the CPU oracle.  Tolerance: north_star's 1e-3 rel (of max)."""
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import nets_ref as N
+from oracle.step_ref import DEFAULT_CFG
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+CRIT = nn.CrossEntropyLoss(ignore_index=255, reduction="none")
+
+
+def sampled(t, n=64):
+    flat = t.detach().reshape(-1)
+    m = min(n, flat.numel())
+    idx = (torch.arange(m, dtype=torch.int64, device=flat.device) * (flat.numel() - 1)) // max(m - 1, 1)
+    return flat[idx]
+
+
+def model_cfg(**kw):
+    d = dict(DEFAULT_CFG)
+    d.update(INIT_MODEL="", OPT_NESTEROV=False)
+    d.update(kw)
+    return NS(**d)
+
+
+def test_resnet101_eval_bn_golden_g2(golden):
+    import models
+    g = golden("g2_resnet101")
+    net = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=True)
+    net.load_state_dict(N.resnet101_state(seed=2, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
+    net.cuda().train()
+    losses, outs = net(T(g["eval_x"]).cuda(), T(g["eval_y"]).cuda())
+    losses["loss_ce"].mean().backward()
+    assert rel_err(outs["logits"], g["eval_logits"]) < 1e-4
+    assert rel_err(sampled(outs["logits_up"], 512), g["eval_logits_up_s"]) < 1e-4
+    assert rel_err(losses["loss_ce"], g["eval_loss"]) < 1e-5
+    named = dict(net.named_parameters())
+    for k in [k[len("eval_g_"):] for k in g.files if k.startswith("eval_g_")]:
+        gn = float(g["eval_gn_" + k])
+        assert abs(float(named[k].grad.norm()) - gn) < 1e-3 * gn, k
+        assert float((sampled(named[k].grad).cpu() - T(g["eval_g_" + k])).abs().max()) < 1e-3 * gn + 1e-7, k
+
+
+def test_resnet101_all_gradients_vs_oracle():
+    """Every one of the 320 parameter gradients against oracle autograd (frozen BN)."""
+    import models
+    sd = N.resnet101_state(seed=5, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 41, 57, generator=g)
+    y = torch.randint(0, 19, (2, 41, 57), generator=g)
+    y[:, :3] = 255
+    ref = {k: v.clone() for k, v in sd.items()}
+    for k in N.trainable_keys(ref):
+        ref[k].requires_grad_(True)
+    losses, _ = N.segnet_forward("deeplabv2_resnet101", ref, x, y)
+    losses["loss_ce"].sum().backward()
+    net = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=True)
+    net.load_state_dict(sd, strict=True)
+    net.cuda().train()
+    l2, _ = net(x.cuda(), y.cuda())
+    l2["loss_ce"].mean().backward()
+    assert rel_err(l2["loss_ce"], losses["loss_ce"]) < 1e-5
+    worst = 0.0
+    for k, p in net.named_parameters():
+        e = rel_err(p.grad, ref[k].grad)
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)
+    print("worst gradient rel err", worst)
+
+
+def test_vgg16_deeplab_cfg1_golden_g10(golden):
+    import models
+    g = golden("g10_vgg16_deeplab")
+    net = models.DeepLabV2_VGG16(num_classes=19, criterion=CRIT, use_bn=True, freeze_bn=True)
+    net.load_state_dict(N.deeplab_vgg16_state(seed=10, randomize_bn=True), strict=True)
+    net.cuda().train()
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(1, 3, 321, 321, generator=gen)
+    y = torch.randint(0, 19, (1, 321, 321), generator=gen)
+    losses, outs = net(x.cuda(), y.cuda())
+    losses["loss_ce"].mean().backward()
+    assert rel_err(outs["logits"], g["logits"]) < 1e-4
+    assert rel_err(losses["loss_ce"], g["loss"]) < 1e-5
+    named = dict(net.named_parameters())
+    assert rel_err(sampled(named["features.0.weight"].grad), g["g_first"]) < 2e-3
+    assert rel_err(sampled(named["features.42.weight"].grad), g["g_fc6"]) < 2e-3
+    assert rel_err(named["classifier.conv2d_list.2.bias"].grad, g["g_cls_bias"]) < 1e-3
+
+
+def test_fcn8s_golden_g10(golden):
+    import models
+    g = golden("g10_fcn8s")
+    net = models.VGG16_FCN8s(19, criterion=CRIT, use_bn=True, freeze_bn=True, drop_rate=0.0)
+    net.load_state_dict(N.fcn8s_vgg16_state(seed=12, randomize_bn=True), strict=True)
+    net.cuda().train()
+    losses, outs = net(T(g["x"]).cuda(), T(g["y"]).cuda())
+    assert set(outs) == {"logits_up"}
+    losses["loss_ce"].mean().backward()
+    assert rel_err(outs["logits_up"], g["logits_up"]) < 1e-4
+    assert rel_err(losses["loss_ce"], g["loss"]) < 1e-5
+    named = dict(net.named_parameters())
+    assert rel_err(sampled(named["vgg_head.0.weight"].grad), g["g_head0"]) < 2e-3
+    assert rel_err(named["score_pool3.weight"].grad.reshape(-1)[:64], g["g_sp3"]) < 2e-3
+    assert rel_err(sampled(named["block1.0.weight"].grad), g["g_first"]) < 2e-3
+
+
+def test_two_sac_training_steps_golden_g8(golden):
+    """train.py:266-298 twice on the HIP path vs the reference's own two steps."""
+    import models
+    import driver
+    g = golden("g8_two_steps")
+    cfg = model_cfg()
+    net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT)
+    net.backbone.load_state_dict(N.resnet101_state(seed=8, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
+    net.cuda().train()
+    optim = driver.make_optimizer(net, cfg)
+    aff, inv = T(g["affine"]).cuda(), T(g["affine_inv"]).cuda()
+    for it in range(2):
+        src = (T(g["it%d_xs" % it]).cuda(), T(g["it%d_ys" % it]).cuda())
+        tgt = (T(g["it%d_f1" % it]).cuda(), T(g["it%d_gt" % it]).cuda(), T(g["it%d_f2" % it]).cuda(), aff, inv)
+        ls, lt, outs = driver.sac_train_iteration(net, optim, src, tgt, int(g["T"]), it % 100 == 0, cfg.LR_TARGET)
+        assert float(ls["loss_ce"]) == pytest.approx(float(g["it%d_src_loss" % it].item()), rel=1e-4)
+        for k in ("loss_ce", "self_ce", "teacher_diff"):
+            assert float(lt[k]) == pytest.approx(float(g["it%d_%s" % (it, k)].item()), rel=2e-3, abs=1e-6), (it, k)
+        mism = (outs["teacher_labels"].to(torch.uint8).cpu() != T(g["it%d_labels" % it])).float().mean()
+        assert mism < 1e-3, (it, float(mism))
+        assert outs["teacher_labels"].dtype == torch.int64
+        assert rel_err(net.running_conf, g["it%d_chi" % it]) < 1e-4
+        st = net.backbone.state_dict()
+        for k in [k[len("it0_p_"):] for k in g.files if k.startswith("it0_p_")]:
+            assert rel_err(sampled(st[k]), g["it%d_p_%s" % (it, k)]) < 1e-4, (it, k)
+        for key in ("logits_up", "logits", "teacher_init", "teacher_refined", "teacher_conf", "teacher_labels",
+                    "running_conf", "teacher_aligned", "frames_aligned"):
+            assert outs[key].is_contiguous(), key
+
+
+def test_inference_paths_and_no_grad():
+    import models
+    cfg = model_cfg()
+    net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT).cuda().eval()
+    x = torch.randn(1, 3, 33, 49, device="cuda")
+    with torch.no_grad():
+        logits, up = net(x, teacher=False)
+        l2, up2 = net(x, teacher=True)
+    assert logits.shape == (1, 19, 5, 7) and up.shape == (1, 19, 33, 49) and l2.shape == logits.shape
