@@ -1,0 +1,152 @@
+"""Headline benchmark: train images/sec of the da-sac per-step hot path on MI355X.
+
+Workload (BASELINE.json configs[2], "cfg-3"): ResNet-101 DeepLabv2 + SAC, per GPU 8 source crops +
+2 groups x 4 views of target crops at 769x769, 19 classes, frozen BN, fp32.  One step =
+source fwd/bwd -> target fwd (teacher fwd + fusion + pseudo labels) -> target bwd -> SGD step
+(reference train.py:266-298).  images/sec follows the reference's counter (source images only,
+train.py:314); N>1 is weak scaling under DistributedDataParallel over RCCL.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 769] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "da-sac_amd"))
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def model_cfg():
+    from types import SimpleNamespace as NS
+    # core/config.py:130-159 + configs/deeplabv2_resnet101_train.yaml
+    return NS(ARCH="deeplabv2_resnet101", INIT_MODEL="", BASELINE=False, LR=2.5e-4, LR_TARGET=5.0, WEIGHT_DECAY=5e-4,
+              MOMENTUM=0.9, OPT_NESTEROV=False, STAT_MOMENTUM=0.99, NET_MOMENTUM=0.99, NET_MOMENTUM_ITER=100,
+              CONF_DISCOUNT=True, CONF_POOL_ON=True, CONF_POOL="avg_pool", FOCAL_P=3, LOSS="focal_ce_conf",
+              RUN_CONF_UPPER=0.75, RUN_CONF_LOWER=0.2, THRESHOLD_BETA=1e-3)
+
+
+def cpu_baseline(size):
+    """The CPU oracle (a port of the reference's path, validated against it by tests/) timed on this host's
+    cores on 1/8 of a cfg-3 step: 1 source crop fwd+bwd, 1 target crop student fwd+bwd, 1 teacher fwd + head."""
+    from oracle import nets_ref as N
+    from oracle.step_ref import SacOracle, SgdOracle, sac_train_iteration
+    import driver
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = SacOracle(N.resnet101_state(seed=0, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2))
+    opt = SgdOracle(m)
+    src, tgt = driver.synthetic_batches(1, 1, 1, (size, size), "cpu", seed=1)
+    m.running_conf.fill_(0.05)
+    m.slow_init[0] = 1.0
+    t0 = time.time()
+    sac_train_iteration(m, opt, src, tgt, 1, update_teacher=False)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1/8 of one cfg-3 step at {0}x{0} (1 source + 1 target crop student fwd+bwd, 1 teacher fwd, head, SGD), "
+                      "one un-warmed run, {1:.1f} s".format(size, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=769)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--groups", type=int, default=2)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import models
+    import driver
+    from dasac_hip import ops
+
+    cfg = model_cfg()
+    if rank != 0:
+        sys.stdout = open(os.devnull, "w")
+    net = models.get_model(cfg, local, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    driver.init_synthetic_weights(net, seed=0)
+    net.cuda(local).train()
+    net.running_conf.fill_(0.05)
+    optim = driver.make_optimizer(net, cfg)
+    step_net = nn.parallel.DistributedDataParallel(net, device_ids=[local]) if world > 1 else net
+    src, tgt = driver.synthetic_batches(args.batch, args.groups, args.views, (args.size, args.size), dev, seed=rank)
+    src = (src[0], driver.self_consistent_labels(net, src[0]))
+
+    def step(i):
+        tgt_i = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])      # forward rewrites -1 -> 255 in place
+        return driver.sac_train_iteration(step_net, optim, src, tgt_i, args.views, update_teacher=(i == 0),
+                                          lr_target=cfg.LR_TARGET)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ops.PROFILE.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ops.PROFILE.stop()
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    losses = {k: float(v.detach().mean()) for k, v in out[1].items()}
+    labelled = float((out[2]["teacher_labels"] != 255).float().mean())
+
+    if rank == 0:
+        sys.stdout = sys.__stdout__
+        dom = prof.get("conv_gemm", {"flops": 0.0, "seconds": 1.0, "launches": 0})
+        ach = dom["flops"] / max(dom["seconds"], 1e-12) / 1e12
+        line = {
+            "metric": "train images/sec (769x769, 19-cls, RN101 DeepLabv2, K=3)",
+            "value": round(world * args.batch * args.steps / dt, 4), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg-3: RN101-DeepLabv2 + SAC, per GPU {} source + {}x{} target crops @{}x{}, frozen BN, "
+                                   "random-init weights".format(args.batch, args.groups, args.views, args.size, args.size),
+                       "global_batch": world * args.batch, "crops_per_step": world * (args.batch + args.groups * args.views),
+                       "parallelism": "dp{}".format(world)},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "dasac::conv_gemm (fwd + dgrad implicit GEMM, fp32 MFMA)",
+                         "launches": dom["launches"], "avg_launch_ms": round(dom["seconds"] / max(dom["launches"], 1) * 1e3, 4)},
+            "kernels": {k: {"tflops": round(v["flops"] / max(v["seconds"], 1e-12) / 1e12, 2), "ms_per_step": round(v["seconds"] / args.steps * 1e3, 2),
+                            "launches_per_step": v["launches"] // args.steps} for k, v in prof.items()},
+            "check": {"self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"), "labelled_frac": round(labelled, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.size)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

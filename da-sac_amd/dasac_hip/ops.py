@@ -8,6 +8,58 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _Profile:
+    """Optional per-launch HIP-event timing of the GEMM kernels (bench.py's roofline leg).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream); off by default."""
+
+    def __init__(self):
+        self.on, self.records = False, []
+
+    def start(self):
+        self.on, self.records = True, []
+
+    def stop(self):
+        self.on = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, a, b in self.records:
+            d = out.setdefault(name, {"flops": 0.0, "seconds": 0.0, "launches": 0})
+            d["flops"] += flops
+            d["seconds"] += a.elapsed_time(b) * 1e-3
+            d["launches"] += 1
+        self.records = []
+        return out
+
+    def span(self, name, flops):
+        return _Span(self, name, flops) if self.on else _NULL
+
+
+class _Span:
+    def __init__(self, prof, name, flops):
+        self.prof, self.name, self.flops = prof, name, flops
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        self.prof.records.append((self.name, self.flops, self.a, b))
+
+
+class _Null:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        pass
+
+
+_NULL = _Null()
+PROFILE = _Profile()
+
+
 def pseudo_labels(probs, ignore, upper, lower, disc=None, want_idx=False):
     """models/sac.py:154-187.  probs [B,C,H,W] f32 cuda; ignore bool [B,H,W] or None; disc [C] or None.
     Returns (labels i64 [B,H,W], max_conf f32 [B,1,H,W], max_idx i64 [B,1,H,W] or None)."""
@@ -92,9 +144,10 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, scale=Non
     assert out.shape[0] == Nb and out.shape[1] == M and x.is_contiguous() and out.is_contiguous()
     for t_ in (res, mask):
         assert t_ is None or (t_.shape == out.shape and t_.is_contiguous())
-    L.check(lib.dasac_conv_gemm(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
-                                stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(scale), L.ptr(shift), L.ptr(res),
-                                L.ptr(mask), int(relu), L.stream_ptr()), "dasac_conv_gemm")
+    with PROFILE.span("conv_gemm", 2.0 * Nb * OH * OW * M * K):
+        L.check(lib.dasac_conv_gemm(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
+                                    stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(scale), L.ptr(shift), L.ptr(res),
+                                    L.ptr(mask), int(relu), L.stream_ptr()), "dasac_conv_gemm")
     return out
 
 
@@ -139,8 +192,9 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None):
     table = conv_table(spec, H, W, False, x.device) if table is None else table
     nbytes = lib.dasac_conv_wgrad_workspace(Nb, OH, OW, M, spec.K)
     ws = L.workspace(nbytes, x.device)
-    L.check(lib.dasac_conv_wgrad(_c(dz).data_ptr(), x.data_ptr(), table.data_ptr(), Nb, Cx, H, W, OH, OW, spec.stride, M,
-                                 spec.K, ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
+    with PROFILE.span("conv_wgrad", 2.0 * Nb * OH * OW * M * spec.K):
+        L.check(lib.dasac_conv_wgrad(_c(dz).data_ptr(), x.data_ptr(), table.data_ptr(), Nb, Cx, H, W, OH, OW, spec.stride, M,
+                                     spec.K, ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
     grads, tap0 = [], 0
     for w, (kh, kw, _, _) in zip(weights, spec.branches):
         dw = torch.empty_like(w)

@@ -41,3 +41,102 @@ def baseline_train_iteration(net, optim, src_batch, tgt_images):
         dummy = torch.zeros(tgt_images.shape[0], tgt_images.shape[2], tgt_images.shape[3], dtype=torch.int64, device=tgt_images.device)
         net(tgt_images, dummy)
     return losses
+
+
+# --------------------------------------------------------------------------------------------------
+# synthetic workload: weights, crops, labels and the four view affines
+# --------------------------------------------------------------------------------------------------
+def init_synthetic_weights(net, seed=0, classifier_gain=6.0):
+    """Random-init weights of the right architecture, scaled like a trained network so that the
+    reference's SGD hyper-parameters are stable: He-normal convs, BN gamma~U(.5,1.5), beta/mean~N(0,.1),
+    var~U(.5,1.5); the BN that closes each residual branch x0.1 and the shortcut BN x0.3 keep the
+    residual stream at E[f^2]~0.05-0.3 (full-range fp32 data, nothing zero-filled); classifier weights
+    x6 give stride-8 logits of std~3 (peaked, unsaturated softmax: ~1/3 of the pseudo-labels fire)."""
+    import torch.nn as nn
+    gen = torch.Generator().manual_seed(seed)
+    core = net.backbone if hasattr(net, "backbone") else net
+    with torch.no_grad():
+        for name, m in core.named_modules():
+            if isinstance(m, nn.Conv2d):
+                fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+                w = torch.empty(m.weight.shape).normal_(0, (2.0 / fan_in) ** 0.5, generator=gen)
+                if "conv2d_list" in name or name.startswith(("score_pool", "vgg_head.8")):
+                    w *= classifier_gain
+                m.weight.copy_(w)
+                if m.bias is not None:
+                    m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.01, generator=gen))
+            elif isinstance(m, (nn.SyncBatchNorm, nn.BatchNorm2d)):
+                gain = 0.1 if name.endswith("bn3") else (0.3 if name.endswith("downsample.1") else 1.0)
+                bgain = 0.3 if name.endswith("downsample.1") else 1.0
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(0.5, 1.5, generator=gen) * gain)
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.1, generator=gen) * bgain)
+                m.running_mean.copy_(torch.empty(m.bias.shape).normal_(0, 0.1, generator=gen))
+                m.running_var.copy_(torch.empty(m.bias.shape).uniform_(0.5, 1.5, generator=gen))
+    return net
+
+
+def view_affines(params, crop_h, crop_w):
+    """theta / theta^-1 [L,2,3] of the augmented views, params = (dy, dx, alpha_deg, scale, flip) per view
+    -- the formulas of /root/reference/datasets/dataloader_target.py:220-262."""
+    import math
+    L = len(params)
+    theta = torch.zeros(L, 2, 3)
+    ar = float(crop_h) / float(crop_w)
+    for i, (dy, dx, alpha, scale, flip) in enumerate(params):
+        s, c = math.sin(alpha * math.pi / 180.0), math.cos(alpha * math.pi / 180.0)
+        theta[i, 0, 0], theta[i, 0, 1] = flip * c, s * ar
+        theta[i, 1, 0], theta[i, 1, 1] = -s / ar, c
+        theta[i, 0, 2] = -(c * dx + s * dy) / float(crop_w // 2)
+        theta[i, 1, 2] = -(-s * dx + c * dy) / float(crop_h // 2)
+        theta[i] *= scale
+    inv = theta.clone()
+    inv[:, 0, 1] = theta[:, 1, 0] * ar ** 2
+    inv[:, 1, 0] = theta[:, 0, 1] / ar ** 2
+    inv[:, 0, 2] = -(inv[:, 0, 0] * theta[:, 0, 2] + inv[:, 0, 1] * theta[:, 1, 2])
+    inv[:, 1, 2] = -(inv[:, 1, 0] * theta[:, 0, 2] + inv[:, 1, 1] * theta[:, 1, 2])
+    inv /= torch.tensor([p[3] for p in params], dtype=torch.float32).view(-1, 1, 1) ** 2
+    return theta, inv
+
+
+# identity | zoom .7 + shift + flip | zoom .5 + shift | flip only   (SURVEY.md 8d)
+BENCH_VIEWS = [(0.0, 0.0, 0.0, 1.0, 1.0), (40.0, -100.0, 0.0, 0.7, -1.0), (-60.0, 30.0, 0.0, 0.5, 1.0), (0.0, 0.0, 0.0, 1.0, -1.0)]
+
+
+def synthetic_batches(batch, groups, views, size, device, seed=0, num_classes=19):
+    """(source batch, target batch) of the cfg-3 shape: N(0,1) crops, random labels with a 16-px ignore
+    border, target labels with 3 padded (-1) rows, frames2 = frames1 + 0.01*noise."""
+    H, W = size
+    gen = torch.Generator().manual_seed(seed)
+    xs = torch.randn(batch, 3, H, W, generator=gen)
+    ys = torch.randint(0, num_classes, (batch, H, W), generator=gen)
+    ys[:, :16] = 255
+    ys[:, -16:] = 255
+    ys[:, :, :16] = 255
+    ys[:, :, -16:] = 255
+    B = groups * views
+    f1 = torch.randn(B, 3, H, W, generator=gen)
+    f2 = f1 + 0.01 * torch.randn(B, 3, H, W, generator=gen)
+    gt = torch.randint(0, num_classes, (B, H, W), generator=gen)
+    gt[:, :3] = -1
+    sc = min(H, W) / 769.0
+    params = [(dy * sc, dx * sc, a, s, f) for (dy, dx, a, s, f) in BENCH_VIEWS[:views]]
+    theta, inv = view_affines(params, H, W)
+    to = lambda t: t.to(device)
+    return (to(xs), to(ys)), (to(f1), to(gt), to(f2), to(theta.repeat(groups, 1, 1)), to(inv.repeat(groups, 1, 1)))
+
+
+def self_consistent_labels(net, images, border=16):
+    """Source labels = the freshly initialised network's own argmax (with the ignore border): a
+    converged-model regime, so that the reference's SGD hyper-parameters (LR 2.5e-4, x10 on the
+    classifier, LR_TARGET 5) stay numerically stable on synthetic data for any number of steps."""
+    core = net.backbone if hasattr(net, "backbone") else net
+    was = core.training
+    core.eval()
+    with torch.no_grad():
+        ys = torch.cat([core(images[i:i + 1])[1].argmax(1) for i in range(images.shape[0])], 0)
+    core.train(was)
+    ys[:, :border] = 255
+    ys[:, -border:] = 255
+    ys[:, :, :border] = 255
+    ys[:, :, -border:] = 255
+    return ys
