@@ -21,6 +21,7 @@
 namespace dasac {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 16;            // K-step of the forward/dgrad kernel
 constexpr int kThreads = 256;      // 4 waves
@@ -48,6 +49,12 @@ struct Epilogue {
 // ------------------------------------------------------------------------------------------
 // forward / dgrad kernel
 // ------------------------------------------------------------------------------------------
+// LDS tiles are k-interleaved: element (k, x) of a K-step lives at [(k/4)][x][k%4], so that
+//   * the packed weights (stored the same way in HBM, see pack_weights) move global->LDS as float4,
+//   * a thread that gathered 4 consecutive k rows of one pixel stores them with one ds_write_b128,
+//   * one ds_read_b128 per operand feeds FOUR MFMAs: lane (i, h) reads k = 8g + 4h + {0..3} and MFMA
+//     j of the group contracts the k pair {8g + j, 8g + 4 + j} (any pairing is valid as long as the A
+//     and B operands agree) -- 8 LDS reads per 32 MFMAs instead of 32.
 template <int BM, int BN, int WAVES_M>
 __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
@@ -55,19 +62,19 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int A_VEC = kBK * BM / 4;                    // float4 loads for the weight tile
+  constexpr int KQ = kBK / 4;                                // k quads per K-step
+  constexpr int A_VEC = KQ * BM;                             // float4 per weight tile
   constexpr int A_PER_T = (A_VEC + kThreads - 1) / kThreads;
-  constexpr int B_ROWS_PASS = kThreads / BN > 0 ? kThreads / BN : 1;   // k rows covered per pass
-  constexpr int B_COLS_T = BN / kThreads > 0 ? BN / kThreads : 1;      // pixel columns per thread
-  constexpr int B_LOADS = kBK / B_ROWS_PASS;
-  static_assert(TM >= 1 && TN >= 1, "tile too small");
+  constexpr int B_Q_PASS = kThreads / BN > 0 ? kThreads / BN : 1;   // k quads covered by one pass of the block
+  constexpr int B_QUADS = KQ / B_Q_PASS;                     // quads (of 4 rows) gathered per thread
+  static_assert(TM >= 1 && TN >= 1 && BN <= kThreads && KQ % B_Q_PASS == 0, "tile shape");
 
-  __shared__ float sA[2][kBK * BM];
-  __shared__ float sB[2][kBK * BN];
+  __shared__ f32x4 sA[2][KQ * BM];
+  __shared__ f32x4 sB[2][KQ * BN];
 
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole pixel tiles so that the M
   // tiles sharing an activation tile hit the same L2.
-  int bid = blockIdx.x;
+  const int bid = blockIdx.x;
   const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
   const int n_tile = (slot / m_tiles) * kNumXcd + xcd;
   const int m_tile = slot % m_tiles;
@@ -78,63 +85,65 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
 
-  // ---- per-thread pixel columns of the gather ------------------------------------------
+  // ---- this thread's pixel column of the gather ---------------------------------------------
   const int OHW = g.OH * g.OW;
-  int pixbase[B_COLS_T], ih0[B_COLS_T], iw0[B_COLS_T];
-  const int bcol0 = (BN >= kThreads) ? t : (t % BN);
-  const int brow0 = (BN >= kThreads) ? 0 : __builtin_amdgcn_readfirstlane(t / BN);
-#pragma unroll
-  for (int c = 0; c < B_COLS_T; ++c) {
-    const int pix = n0 + bcol0 + c * kThreads;
+  const int bcol = t % BN;
+  const int bq0 = __builtin_amdgcn_readfirstlane(t / BN);    // wave-uniform first quad
+  int pixbase, ih0, iw0;
+  {
+    const int pix = n0 + bcol;
     if (pix < g.Npix) {
       const int n = pix / OHW, r = pix - n * OHW;
       const int oh = r / g.OW, ow = r - oh * g.OW;
-      ih0[c] = oh * g.stride;
-      iw0[c] = ow * g.stride;
-      pixbase[c] = n * g.CxHW + ih0[c] * g.W + iw0[c];
+      ih0 = oh * g.stride;
+      iw0 = ow * g.stride;
+      pixbase = n * g.CxHW + ih0 * g.W + iw0;
     } else {
-      ih0[c] = -kInvalid;
-      iw0[c] = 0;
-      pixbase[c] = 0;
+      ih0 = -kInvalid;
+      iw0 = 0;
+      pixbase = 0;
     }
   }
+  const f32x4* __restrict__ Wp4 = reinterpret_cast<const f32x4*>(Wp);
+  // out-of-bounds taps read a 0.0f that lives in the table itself (every row's 4th word is 0): the
+  // select happens on the ADDRESS, so nothing has to wait for the loaded value before the MFMAs.
+  const float* __restrict__ zero_src = reinterpret_cast<const float*>(tab) + 3;
 
-  float4 ra[A_PER_T];
-  float rb[B_LOADS * B_COLS_T];
+  f32x4 ra[A_PER_T];
+  f32x4 rb[B_QUADS];
 
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * kBK;
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int v = t + i * kThreads;
-      if (A_VEC % kThreads == 0 || v < A_VEC) {
-        const int row = v / (BM / 4), c4 = v % (BM / 4);
-        ra[i] = *reinterpret_cast<const float4*>(Wp + (size_t)(k0 + row) * g.Mpad + m0 + c4 * 4);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < B_LOADS; ++r) {
-      const int4 e = tab[k0 + brow0 + r * B_ROWS_PASS];   // wave-uniform -> scalar load
-#pragma unroll
-      for (int c = 0; c < B_COLS_T; ++c) {
-        const int ih = ih0[c] + e.y, iw = iw0[c] + e.z;
-        const bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-        rb[r * B_COLS_T + c] = ok ? X[pixbase[c] + e.x] : 0.f;
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int v = t + i * kThreads;
-      if (A_VEC % kThreads == 0 || v < A_VEC) *reinterpret_cast<float4*>(&sA[buf][v * 4]) = ra[i];
-    }
-#pragma unroll
-    for (int r = 0; r < B_LOADS; ++r)
-#pragma unroll
-      for (int c = 0; c < B_COLS_T; ++c)
-        sB[buf][(brow0 + r * B_ROWS_PASS) * BN + bcol0 + c * kThreads] = rb[r * B_COLS_T + c];
-  };
+  // branch-free gather of one K-step into registers (loads stay in flight while the MFMAs issue)
+#define DASAC_LOAD_TILE(kt)                                                                          \
+  {                                                                                                  \
+    const int kq0 = (kt) * KQ;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < A_PER_T; ++i) {                                            \
+      const int v = t + i * kThreads;                                                                \
+      if (A_VEC % kThreads == 0 || v < A_VEC) {                                                      \
+        const int q = v / BM, m = v - q * BM;                                                        \
+        ra[i] = Wp4[(size_t)(kq0 + q) * g.Mpad + m0 + m];                                            \
+      }                                                                                              \
+    }                                                                                                \
+    int4 te[B_QUADS * 4]; /* all table rows of this K-step first: one batch of scalar loads */       \
+    _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r)                                              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) te[r * 4 + j] = tab[(kq0 + bq0 + r * B_Q_PASS) * 4 + j]; \
+    _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+        const int4 e = te[r * 4 + j];                                                                \
+        const int ih = ih0 + e.y, iw = iw0 + e.z;                                                    \
+        const bool ok = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);             \
+        const float* src = ok ? X + (pixbase + e.x) : zero_src;                                      \
+        rb[r][j] = *src;                                                                             \
+      }                                                                                              \
+    }                                                                                                \
+  }
+#define DASAC_STORE_TILE(buf)                                                                        \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < A_PER_T; ++i) {                                            \
+      const int v = t + i * kThreads;                                                                \
+      if (A_VEC % kThreads == 0 || v < A_VEC) sA[buf][v] = ra[i];                                    \
+    }                                                                                                \
+    _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) sB[buf][(bq0 + r * B_Q_PASS) * BN + bcol] = rb[r]; \
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -145,29 +154,40 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int KT = g.Kpad / kBK;
-  load_tile(0);
-  store_tile(0);
+  DASAC_LOAD_TILE(0);
+  DASAC_STORE_TILE(0);
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
-    const float* a_base = &sA[buf][wm * WM + li];
-    const float* b_base = &sB[buf][wn * WN + li];
+    const bool more = kt + 1 < KT;
+    if (more) DASAC_LOAD_TILE(kt + 1);
+    // all fragments of the K-step first (8 x ds_read_b128), then the MFMA chain
+    f32x4 a4[kBK / 8][TM], b4[kBK / 8][TN];
 #pragma unroll
-    for (int kk = 0; kk < kBK / 2; ++kk) {
-      float a[TM], b[TN];
+    for (int gq = 0; gq < kBK / 8; ++gq) {
+      const int q = 2 * gq + lh;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = a_base[(2 * kk + lh) * BM + i * 32];
+      for (int i = 0; i < TM; ++i) a4[gq][i] = sA[buf][q * BM + wm * WM + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = b_base[(2 * kk + lh) * BN + j * 32];
+      for (int j = 0; j < TN; ++j) b4[gq][j] = sB[buf][q * BN + wn * WN + j * 32 + li];
+    }
+#pragma unroll
+    for (int gq = 0; gq < kBK / 8; ++gq) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].x, b4[gq][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].y, b4[gq][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].z, b4[gq][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].w, b4[gq][j].w, acc[i][j], 0, 0, 0);
+        }
     }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
+    if (more) DASAC_STORE_TILE(buf ^ 1);
     __syncthreads();
   }
+#undef DASAC_LOAD_TILE
+#undef DASAC_STORE_TILE
 
   // ---- epilogue: BN(eval) scale/shift | bias, residual, ReLU, ReLU-backward mask -----------
   const int OutHW = g.OutH * g.OutW;
@@ -209,7 +229,8 @@ constexpr int kWgPitch = 33;
 template <int BM, int BN, int WAVES_M>
 __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
-                                                       GemmGeom g, int m_tiles, int k_tiles, int pix_per_split) {
+                                                       float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
+                                                       int pix_per_split) {
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -231,12 +252,20 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
   const int p_end = min(p_begin + pix_per_split, g.Npix);
   const int steps = (p_end - p_begin + kWgPix - 1) / kWgPix;
 
-  // table rows of this thread's B loads are fixed for the whole kernel
-  int4 te[B_LOADS];
+  // table rows of this thread's B loads are fixed for the whole kernel: keep (offset, dh:dw) packed
+  int te_off[B_LOADS], te_d[B_LOADS];
 #pragma unroll
-  for (int r = 0; r < B_LOADS; ++r) te[r] = tab[kb0 + prow + r * 8];
+  for (int r = 0; r < B_LOADS; ++r) {
+    const int4 e = tab[kb0 + prow + r * 8];
+    te_off[r] = e.x;
+    te_d[r] = e.y >= kInvalid ? (int)0x80000000 : ((e.y << 16) | (e.z & 0xffff));   // dh = -32768 never in bounds
+  }
 
   float ra[A_LOADS], rb[B_LOADS];
+  float rsum[A_LOADS];                                   // per-row sums of dZ (only the k_tile 0 blocks)
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) rsum[i] = 0.f;
+  const bool do_sums = (k_tile == 0) && (Psum != nullptr);
   const int zimg = g.M * OHW;                            // dZ image stride
 
   auto load_tile = [&](int s) {
@@ -255,13 +284,17 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int m = m0 + prow + i * 8;
-      ra[i] = (pv && m < g.M) ? dZ[zbase + m * OHW] : 0.f;
+      const bool okm = pv & (m < g.M);
+      const float zv = dZ[okm ? zbase + m * OHW : 0];
+      ra[i] = okm ? zv : 0.f;
+      if (do_sums) rsum[i] += ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-      const int ih = ih0 + te[i].y, iw = iw0 + te[i].z;
-      const bool ok = pv && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-      rb[i] = ok ? X[xbase + te[i].x] : 0.f;
+      const int ih = ih0 + (te_d[i] >> 16), iw = iw0 + (int)(short)(te_d[i] & 0xffff);
+      const bool ok = pv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
+      const float xv = X[ok ? xbase + te_off[i] : 0];
+      rb[i] = ok ? xv : 0.f;
     }
   };
   auto store_tile = [&](int buf) {
@@ -305,6 +338,16 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
     __syncthreads();
   }
 
+  if (do_sums) {
+    // the 32 lanes of a half-wave hold the 32 pixels of the same rows: butterfly inside the half
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      float v = rsum[i];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (pl == 0) Psum[(size_t)split * g.Mpad + m0 + prow + i * 8] = v;
+    }
+  }
   // partial slab [split][Mpad][Kpad], k contiguous
   float* slab = P + (size_t)split * g.Mpad * g.Kpad;
 #pragma unroll
@@ -367,17 +410,24 @@ __global__ void pack_weights(const float* __restrict__ Wt, const float* __restri
         if (scale) v = v * scale[c];
       }
     }
-    Wp[(int64_t)(tap0 * C + row) * Mpad + m] = v;
+    const int64_t k = (int64_t)tap0 * C + row;
+    Wp[((k >> 2) * Mpad + m) * 4 + (k & 3)] = v;   // k-interleaved: [(k/4)][m][k%4]
   }
 }
 
 // dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G)
 // one block per output channel.
-__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P, int splits, int Mpad, int Kpad,
-                                                    const float* __restrict__ Wt, const float* __restrict__ scale,
-                                                    float* __restrict__ dW, float* __restrict__ dot, int Cin, int taps,
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P, const float* __restrict__ Psum, int splits,
+                                                    int Mpad, int Kpad, const float* __restrict__ Wt,
+                                                    const float* __restrict__ scale, float* __restrict__ dW,
+                                                    float* __restrict__ dot, float* __restrict__ sum_dz, int Cin, int taps,
                                                     int tap0) {
   const int co = blockIdx.x;
+  if (sum_dz && threadIdx.x == 0) {
+    float sv = 0.f;
+    for (int s = 0; s < splits; ++s) sv += Psum[(size_t)s * Mpad + co];
+    sum_dz[co] = sv;
+  }
   const int n = Cin * taps;
   const float sc = scale ? scale[co] : 1.f;
   float part = 0.f;
@@ -423,11 +473,11 @@ static void launch_gemm(const float* X, const float* Wp, const int4* tab, float*
 }
 
 template <int BM, int BN, int WAVES_M>
-static void launch_wgrad(const float* dZ, const float* X, const int4* tab, float* P, const GemmGeom& g, int splits,
-                         int pix_per_split, hipStream_t s) {
+static void launch_wgrad(const float* dZ, const float* X, const int4* tab, float* P, float* Psum, const GemmGeom& g,
+                         int splits, int pix_per_split, hipStream_t s) {
   const int m_tiles = g.Mpad / BM, k_tiles = g.Kpad / BN;
-  hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P, g,
-                     m_tiles, k_tiles, pix_per_split);
+  hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P, Psum,
+                     g, m_tiles, k_tiles, pix_per_split);
 }
 
 }  // namespace dasac
@@ -466,7 +516,7 @@ extern "C" int dasac_conv_pack(const float* w, const float* scale, int Cout, int
   const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
   const int Mpad = dasac_conv_mpad(M), K = total_taps * C, Kpad = dasac_conv_kpad(K);
   hipStream_t s = as_stream(stream);
-  if (tap0 == 0 && Kpad > K) DASAC_HIP(hipMemsetAsync(packed + (size_t)K * Mpad, 0, (size_t)(Kpad - K) * Mpad * sizeof(float), s));
+  if (tap0 == 0 && Kpad > K) DASAC_HIP(hipMemsetAsync(packed, 0, (size_t)Kpad * Mpad * sizeof(float), s));   // zero K padding
   const int64_t total = (int64_t)taps * C * Mpad;
   hipLaunchKernelGGL(pack_weights, dim3(stream_grid(total, 256)), dim3(256), 0, s, w, scale, packed, Cout, Cin, taps, tap0,
                      Mpad, transposed ? 1 : 0);
@@ -507,7 +557,7 @@ static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM) {
 extern "C" size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K) {
   const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
   const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
-  return (size_t)splits * Mpad * Kpad * sizeof(float);
+  return (size_t)splits * Mpad * (Kpad + 1) * sizeof(float);     // slabs + per-split channel sums
 }
 
 // dz [Nb,M,OH,OW], x [Nb,Cx,H,W] -> slabs in workspace -> dW (one or several weight tensors of a fused conv)
@@ -520,29 +570,31 @@ extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* 
   if (rc) return rc;
   const int bm = pick_bm(Mpad);
   const int splits = wgrad_splits(Mpad, Kpad, g.Npix, bm);
-  if (ws_bytes < (size_t)splits * Mpad * Kpad * sizeof(float)) return fail(DASAC_EWORKSPACE, "conv_wgrad: workspace too small");
+  if (ws_bytes < (size_t)splits * Mpad * (Kpad + 1) * sizeof(float)) return fail(DASAC_EWORKSPACE, "conv_wgrad: workspace too small");
   int per = (g.Npix + splits - 1) / splits;
   per = (per + kWgPix - 1) / kWgPix * kWgPix;
   const int4* tab = reinterpret_cast<const int4*>(table);
   float* P = reinterpret_cast<float*>(workspace);
+  float* Psum = P + (size_t)splits * Mpad * Kpad;
   hipStream_t s = as_stream(stream);
   switch (bm) {
-    case 128: launch_wgrad<128, 128, 2>(dz, x, tab, P, g, splits, per, s); break;
-    case 64: launch_wgrad<64, 128, 2>(dz, x, tab, P, g, splits, per, s); break;
-    default: launch_wgrad<32, 128, 1>(dz, x, tab, P, g, splits, per, s); break;
+    case 128: launch_wgrad<128, 128, 2>(dz, x, tab, P, Psum, g, splits, per, s); break;
+    case 64: launch_wgrad<64, 128, 2>(dz, x, tab, P, Psum, g, splits, per, s); break;
+    default: launch_wgrad<32, 128, 1>(dz, x, tab, P, Psum, g, splits, per, s); break;
   }
   DASAC_CHECK_LAUNCH("conv_wgrad");
   return DASAC_OK;
 }
 
 extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K, const float* w,
-                                       const float* scale, float* dw, float* dot, int Cin, int taps, int tap0,
-                                       dasac_stream_t stream) {
+                                       const float* scale, float* dw, float* dot, float* sum_dz, int Cin, int taps,
+                                       int tap0, dasac_stream_t stream) {
   DASAC_REQUIRE(workspace && w && dw, "conv_wgrad_finish: null pointer");
   const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
   const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
-  hipLaunchKernelGGL(wgrad_reduce, dim3(M), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(workspace), splits,
-                     Mpad, Kpad, w, scale, dw, dot, Cin, taps, tap0);
+  const float* P = reinterpret_cast<const float*>(workspace);
+  hipLaunchKernelGGL(wgrad_reduce, dim3(M), dim3(256), 0, as_stream(stream), P, P + (size_t)splits * Mpad * Kpad, splits, Mpad,
+                     Kpad, w, scale, dw, dot, sum_dz, Cin, taps, tap0);
   DASAC_CHECK_LAUNCH("wgrad_reduce");
   return DASAC_OK;
 }

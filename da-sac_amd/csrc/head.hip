@@ -37,24 +37,32 @@ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
 //   up    [B,C,H,W]  upsampled logits
 //   probs [B,C,H,W]  softmax(up) * (ignore ? 0 : 1)
 //   csum  [C] double class sums of the UNMASKED softmax (running class prior, sac.py:108)
-__global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict__ x, int C, int h, int w, int H, int W,
+// CT = compile-time class count (19 for Cityscapes) so the per-pixel class vector stays in registers.
+template <int CT>
+__global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict__ x, int Crt, int h, int w, int H, int W,
                                                         float sh, float sw, const uint8_t* __restrict__ ignore,
                                                         float* __restrict__ up, float* __restrict__ probs,
                                                         double* __restrict__ csum, int blocks_per_image) {
+  const int C = CT < kMaxC ? CT : Crt;          // CT == kMaxC is the generic (runtime-C) instantiation
   const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
   const int HW = H * W, hw = h * w;
   const float* xb = x + (size_t)b * C * hw;
-  float acc[kMaxC];
+  __shared__ float s_sum[kMaxC];
+  if (csum) {
+    if (threadIdx.x < kMaxC) s_sum[threadIdx.x] = 0.f;
+    __syncthreads();
+  }
+  float acc[CT];
 #pragma unroll
-  for (int c = 0; c < kMaxC; ++c) acc[c] = 0.f;
+  for (int c = 0; c < CT; ++c) acc[c] = 0.f;
   for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
     const int oy = p / W, ox = p - oy * W;
     const Tap ty = tap_ac(oy, sh, h), tx = tap_ac(ox, sw, w);
     const int o00 = ty.i0 * w + tx.i0, o01 = ty.i0 * w + tx.i1, o10 = ty.i1 * w + tx.i0, o11 = ty.i1 * w + tx.i1;
-    float v[kMaxC];
+    float v[CT];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
+    for (int c = 0; c < CT; ++c) {
       if (c < C) {
         const float* pl = xb + (size_t)c * hw;
         const float top = tx.w0 * pl[o00] + tx.w1 * pl[o01];
@@ -66,13 +74,13 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
     const size_t obase = (size_t)b * C * HW + p;
     if (up) {
 #pragma unroll
-      for (int c = 0; c < kMaxC; ++c)
+      for (int c = 0; c < CT; ++c)
         if (c < C) up[obase + (size_t)c * HW] = v[c];
     }
     if (probs || csum) {
       float den = 0.f;
 #pragma unroll
-      for (int c = 0; c < kMaxC; ++c)
+      for (int c = 0; c < CT; ++c)
         if (c < C) {
           v[c] = expf(v[c] - mx);
           den += v[c];
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
       const float inv = 1.f / den;
       const bool ign = ignore && ignore[(size_t)b * HW + p];
 #pragma unroll
-      for (int c = 0; c < kMaxC; ++c)
+      for (int c = 0; c < CT; ++c)
         if (c < C) {
           const float pr = v[c] * inv;
           acc[c] += pr;
@@ -89,20 +97,12 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
     }
   }
   if (csum) {
-    __shared__ double red[kHB / 64][kMaxC];
+    // per-thread partials (a few pixels each) -> LDS float atomics -> one double atomic per class and block
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
-      if (c < C) {
-        const double s = wave_sum((double)acc[c]);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = s;
-      }
-    }
+    for (int c = 0; c < CT; ++c)
+      if (c < C) atomicAdd(&s_sum[c], acc[c]);
     __syncthreads();
-    if (threadIdx.x < C) {
-      double s = 0;
-      for (int wv = 0; wv < kHB / 64; ++wv) s += red[wv][threadIdx.x];
-      atomicAdd(&csum[threadIdx.x], s);
-    }
+    if (threadIdx.x < C) atomicAdd(&csum[threadIdx.x], (double)s_sum[threadIdx.x]);
   }
 }
 
@@ -424,8 +424,12 @@ extern "C" int dasac_upsample_softmax(const float* logits, int B, int C, int h, 
   hipStream_t s = as_stream(stream);
   if (class_sums) DASAC_HIP(hipMemsetAsync(class_sums, 0, C * sizeof(double), s));
   const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
-  hipLaunchKernelGGL(upsample_softmax, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), ac_scale(w, W),
-                     ignore, up, probs, class_sums, per);
+  if (C == 19)
+    hipLaunchKernelGGL(upsample_softmax<19>, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H),
+                       ac_scale(w, W), ignore, up, probs, class_sums, per);
+  else
+    hipLaunchKernelGGL(upsample_softmax<kMaxC>, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H),
+                       ac_scale(w, W), ignore, up, probs, class_sums, per);
   DASAC_CHECK_LAUNCH("upsample_softmax");
   return DASAC_OK;
 }

@@ -283,16 +283,19 @@ class Engine:
                 bn_idx = rest[len(b_idx):]
                 want_bn = op.bn is not None and any(need[j] for j in bn_idx)
                 want_bias = any(need[j] for j in b_idx)
-                sums = ops.channel_sums(dz) if (want_bn or want_bias) else None
-                dot = None
+                sums, dot = None, None
                 if any(w_need) or want_bn:
                     if want_bn:
                         dot = torch.zeros(spec.cout, dtype=torch.float32, device=dz.device)
+                    if want_bn or want_bias:      # channel sums ride along with the wgrad kernel
+                        sums = torch.empty(spec.cout, dtype=torch.float32, device=dz.device)
                     dws = ops.conv_wgrad(spec, dz, xin, [c.weight.detach() for c in op.convs], scale=scale, dot=dot,
-                                         table=self.table(op, H, W, False, xin.device))
+                                         table=self.table(op, H, W, False, xin.device), sum_dz=sums)
                     for j, dw in zip(op.pidx[:nw], dws):
                         if need[j]:
                             grads[j] = dw
+                elif want_bias:
+                    sums = ops.channel_sums(dz)
                 if op.bn is not None:
                     cb = op.convs[0].bias.detach() if op.has_bias else None
                     dg, db, dcb = ops.bn_param_grads(dot, sums, op.bn.running_mean, invstd, scale, cb,

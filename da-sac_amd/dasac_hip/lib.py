@@ -42,7 +42,7 @@ PROTOTYPES = {
     "dasac_scale_planes": (_i, [_p, _p, _l, _l, _p, _p]),
     "dasac_add": (_i, [_p, _p, _p, _l, _p]),
     "dasac_relu_mask": (_i, [_p, _p, _p, _l, _p]),
-    "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 
 

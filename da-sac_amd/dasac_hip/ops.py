@@ -183,8 +183,9 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
     return relu_mask(dx, mask) if mask is not None else dx
 
 
-def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None):
-    """Returns [dW per branch]; optionally accumulates dot[co] += sum_k W*G (unscaled G)."""
+def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=None):
+    """Returns [dW per branch]; optionally accumulates dot[co] += sum_k W*G (unscaled G) and fills
+    sum_dz[co] = sum over batch and pixels of dz."""
     lib = L.load()
     L.require_gpu(dz, x, *weights)
     Nb, Cx, H, W = x.shape
@@ -199,7 +200,8 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None):
     for w, (kh, kw, _, _) in zip(weights, spec.branches):
         dw = torch.empty_like(w)
         L.check(lib.dasac_conv_wgrad_finish(ws.data_ptr(), Nb, OH, OW, M, spec.K, _c(w).data_ptr(), L.ptr(scale),
-                                            dw.data_ptr(), L.ptr(dot), spec.cin, kh * kw, tap0, L.stream_ptr()),
+                                            dw.data_ptr(), L.ptr(dot), L.ptr(sum_dz if tap0 == 0 else None), spec.cin, kh * kw,
+                                            tap0, L.stream_ptr()),
                 "dasac_conv_wgrad_finish")
         grads.append(dw)
         tap0 += kh * kw

@@ -70,7 +70,9 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *                    epi: v*scale[m] + shift[m] (+res) (ReLU) (zeroed where mask <= 0).
  * dasac_conv_wgrad   partial weight gradients (split over pixels) into `workspace`;
  * dasac_conv_wgrad_finish  sums the splits, writes dW[co,ci,kh,kw] = scale[co]*G and, when `dot`
- *                    is given, dot[co] += sum_k W*G (the frozen-BN gamma gradient term).
+ *                    is given, dot[co] += sum_k W*G (the frozen-BN gamma gradient term); `sum_dz`
+ *                    (optional) receives sum over batch and pixels of dz per channel (d beta / d bias),
+ *                    accumulated for free by the wgrad kernel while it streams dz.
  */
 int dasac_conv_mpad(int M);
 int dasac_conv_kpad(int K);
@@ -90,7 +92,7 @@ int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
                      void* workspace, size_t ws_bytes, dasac_stream_t stream);
 int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K,
                             const float* w, const float* scale, float* dw, float* dot,
-                            int Cin, int taps, int tap0, dasac_stream_t stream);
+                            float* sum_dz, int Cin, int taps, int tap0, dasac_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SAC head (models/sac.py) -- HBM-bound streaming kernels over [B,C,H,W] fp32, C <= 32.
