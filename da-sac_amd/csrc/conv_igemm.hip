@@ -18,6 +18,8 @@
 // Roofline: MFMA-bound, 2*M*Npix*K flops per launch against the 157.3 TFLOP/s fp32 matrix peak.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace dasac {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -36,6 +38,7 @@ struct GemmGeom {
   int M, Mpad, Kpad;
   // output tensor [Nb, M, OutH, OutW]; element (oh*ostride, ow*ostride)
   int OutH, OutW, ostride;
+  int x_bytes, w_bytes, z_bytes;  // buffer-descriptor extents (gathered tensor, packed weights, dZ)
 };
 
 struct Epilogue {
@@ -49,21 +52,45 @@ struct Epilogue {
 // ------------------------------------------------------------------------------------------
 // forward / dgrad kernel
 // ------------------------------------------------------------------------------------------
+// Buffer addressing.  Every global read of the GEMM loops goes through a raw buffer descriptor:
+//   address = base + voffset (VGPR) + soffset (SGPR);  reads past num_records return 0.
+// That turns the zero padding of the convolution into an ADDRESS decision (out-of-image taps get the
+// poison offset 2^31 >= num_records) and moves the per-row part of the address (channel plane, K-step
+// of the weights) into the scalar operand -- the vector ALU, which shares issue bandwidth with the
+// matrix pipe (measured: ~6 matrix-pipe cycles lost per VALU instruction), stays almost idle.
+constexpr unsigned kPoison = 0x80000000u;
+constexpr int kRsrcFlags = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family word 3)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, kRsrcFlags);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+
 // LDS tiles are k-interleaved: element (k, x) of a K-step lives at [(k/4)][x][k%4], so that
-//   * the packed weights (stored the same way in HBM, see pack_weights) move global->LDS as float4,
+//   * the packed weights (stored the same way in HBM, see pack_weights) move global->LDS as 16-byte words,
 //   * a thread that gathered 4 consecutive k rows of one pixel stores them with one ds_write_b128,
 //   * one ds_read_b128 per operand feeds FOUR MFMAs: lane (i, h) reads k = 8g + 4h + {0..3} and MFMA
 //     j of the group contracts the k pair {8g + j, 8g + 4 + j} (any pairing is valid as long as the A
 //     and B operands agree) -- 8 LDS reads per 32 MFMAs instead of 32.
-template <int BM, int BN, int WAVES_M>
+// FAST: the gathered tensor's channel count is a multiple of BK, so a K-step never straddles two
+// taps: one (dh, dw) per step, validity and the spatial offset computed once per thread and step, the
+// channel offset of each row rides in the scalar operand (zero VALU per gathered element).
+template <int BM, int BN, int WAVES_M, int BK, bool FAST>
 __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles) {
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int KQ = kBK / 4;                                // k quads per K-step
-  constexpr int A_VEC = KQ * BM;                             // float4 per weight tile
+  constexpr int KQ = BK / 4;                                // k quads per K-step
+  constexpr int A_VEC = KQ * BM;                             // 16-byte words per weight tile
   constexpr int A_PER_T = (A_VEC + kThreads - 1) / kThreads;
   constexpr int B_Q_PASS = kThreads / BN > 0 ? kThreads / BN : 1;   // k quads covered by one pass of the block
   constexpr int B_QUADS = KQ / B_Q_PASS;                     // quads (of 4 rows) gathered per thread
@@ -85,8 +112,12 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
 
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, g.w_bytes);
+
   // ---- this thread's pixel column of the gather ---------------------------------------------
   const int OHW = g.OH * g.OW;
+  const int planeHW = g.H * g.W;
   const int bcol = t % BN;
   const int bq0 = __builtin_amdgcn_readfirstlane(t / BN);    // wave-uniform first quad
   int pixbase, ih0, iw0;
@@ -99,40 +130,50 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
       iw0 = ow * g.stride;
       pixbase = n * g.CxHW + ih0 * g.W + iw0;
     } else {
-      ih0 = -kInvalid;
+      ih0 = -kInvalid;     // every tap out of bounds -> poison offsets -> zeros
       iw0 = 0;
       pixbase = 0;
     }
   }
-  const f32x4* __restrict__ Wp4 = reinterpret_cast<const f32x4*>(Wp);
-  // out-of-bounds taps read a 0.0f that lives in the table itself (every row's 4th word is 0): the
-  // select happens on the ADDRESS, so nothing has to wait for the loaded value before the MFMAs.
-  const float* __restrict__ zero_src = reinterpret_cast<const float*>(tab) + 3;
+  // weight tile: per-thread byte offsets inside a K-step, the K-step itself goes in the scalar offset
+  unsigned voff_a[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int v = t + i * kThreads;
+    const int q = v / BM, m = v - q * BM;
+    voff_a[i] = (unsigned)(q * g.Mpad + m0 + m) * 16u;
+  }
+  const int a_step_bytes = KQ * g.Mpad * 16;
 
   f32x4 ra[A_PER_T];
   f32x4 rb[B_QUADS];
 
-  // branch-free gather of one K-step into registers (loads stay in flight while the MFMAs issue)
 #define DASAC_LOAD_TILE(kt)                                                                          \
   {                                                                                                  \
-    const int kq0 = (kt) * KQ;                                                                       \
     _Pragma("unroll") for (int i = 0; i < A_PER_T; ++i) {                                            \
-      const int v = t + i * kThreads;                                                                \
-      if (A_VEC % kThreads == 0 || v < A_VEC) {                                                      \
-        const int q = v / BM, m = v - q * BM;                                                        \
-        ra[i] = Wp4[(size_t)(kq0 + q) * g.Mpad + m0 + m];                                            \
-      }                                                                                              \
+      if (A_VEC % kThreads == 0 || t + i * kThreads < A_VEC) ra[i] = buf_f32x4(rw, voff_a[i], (kt) * a_step_bytes); \
     }                                                                                                \
-    int4 te[B_QUADS * 4]; /* all table rows of this K-step first: one batch of scalar loads */       \
-    _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r)                                              \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) te[r * 4 + j] = tab[(kq0 + bq0 + r * B_Q_PASS) * 4 + j]; \
-    _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                            \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
-        const int4 e = te[r * 4 + j];                                                                \
-        const int ih = ih0 + e.y, iw = iw0 + e.z;                                                    \
-        const bool ok = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);             \
-        const float* src = ok ? X + (pixbase + e.x) : zero_src;                                      \
-        rb[r][j] = *src;                                                                             \
+    if (FAST) {                                                                                      \
+      const int4 e = tab[(kt) * BK]; /* one tap per K-step: (koff, dh, dw, channel offset) */        \
+      const int ih = ih0 + e.y, iw = iw0 + e.z;                                                      \
+      const bool ok = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);               \
+      const unsigned voff = ok ? (unsigned)(pixbase + (e.x - e.w)) * 4u : kPoison;                   \
+      _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                          \
+        const int row0 = 4 * (bq0 + r * B_Q_PASS);                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+          rb[r][j] = buf_f32(rx, voff, (e.w + (row0 + j) * planeHW) * 4);                            \
+      }                                                                                              \
+    } else {                                                                                         \
+      int4 te[B_QUADS * 4]; /* all table rows of this K-step first: one batch of scalar loads */     \
+      _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r)                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) te[r * 4 + j] = tab[((kt) * KQ + bq0 + r * B_Q_PASS) * 4 + j]; \
+      _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+          const int4 e = te[r * 4 + j];                                                              \
+          const int ih = ih0 + e.y, iw = iw0 + e.z;                                                  \
+          const bool ok = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);           \
+          rb[r][j] = buf_f32(rx, ok ? (unsigned)(pixbase + e.x) * 4u : kPoison, 0);                  \
+        }                                                                                            \
       }                                                                                              \
     }                                                                                                \
   }
@@ -153,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = g.Kpad / kBK;
+  const int KT = g.Kpad / BK;
   DASAC_LOAD_TILE(0);
   DASAC_STORE_TILE(0);
   __syncthreads();
@@ -161,10 +202,9 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
     const int buf = kt & 1;
     const bool more = kt + 1 < KT;
     if (more) DASAC_LOAD_TILE(kt + 1);
-    // all fragments of the K-step first (8 x ds_read_b128), then the MFMA chain
-    f32x4 a4[kBK / 8][TM], b4[kBK / 8][TN];
+    f32x4 a4[BK / 8][TM], b4[BK / 8][TN];
 #pragma unroll
-    for (int gq = 0; gq < kBK / 8; ++gq) {
+    for (int gq = 0; gq < BK / 8; ++gq) {
       const int q = 2 * gq + lh;
 #pragma unroll
       for (int i = 0; i < TM; ++i) a4[gq][i] = sA[buf][q * BM + wm * WM + i * 32 + li];
@@ -172,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
       for (int j = 0; j < TN; ++j) b4[gq][j] = sB[buf][q * BN + wn * WN + j * 32 + li];
     }
 #pragma unroll
-    for (int gq = 0; gq < kBK / 8; ++gq) {
+    for (int gq = 0; gq < BK / 8; ++gq) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -226,7 +266,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
 constexpr int kWgPix = 32;   // pixels per K-step
 constexpr int kWgPitch = 33;
 
-template <int BM, int BN, int WAVES_M>
+// FAST: Cx % BN == 0 (the 128 im2col rows of a block belong to ONE tap) and M % 8 == 0: one (dh, dw)
+// per block, the per-row part of both operand addresses is a scalar offset, the pixel position is
+// advanced incrementally (no divisions in the loop) -> ~25 VALU per 64 MFMAs.
+template <int BM, int BN, int WAVES_M, bool FAST>
 __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
                                                        float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
@@ -247,18 +290,27 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
   const int li = lane & 31, lh = lane >> 5;
   const int pl = t & 31, prow = t >> 5;                  // loader: pixel lane, row within pass
 
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, g.x_bytes);
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(dZ, g.z_bytes);
+
   const int OHW = g.OH * g.OW;
+  const int planeHW = g.H * g.W;
   const int p_begin = split * pix_per_split;
   const int p_end = min(p_begin + pix_per_split, g.Npix);
   const int steps = (p_end - p_begin + kWgPix - 1) / kWgPix;
 
-  // table rows of this thread's B loads are fixed for the whole kernel: keep (offset, dh:dw) packed
-  int te_off[B_LOADS], te_d[B_LOADS];
+  // generic path: table rows of this thread's B loads are fixed for the whole kernel (offset, dh:dw packed)
+  int te_off[FAST ? 1 : B_LOADS], te_d[FAST ? 1 : B_LOADS];
+  int4 e0 = make_int4(0, 0, 0, 0);
+  if (FAST) {
+    e0 = tab[kb0];                                       // the block's tap: (koff, dh, dw, channel offset)
+  } else {
 #pragma unroll
-  for (int r = 0; r < B_LOADS; ++r) {
-    const int4 e = tab[kb0 + prow + r * 8];
-    te_off[r] = e.x;
-    te_d[r] = e.y >= kInvalid ? (int)0x80000000 : ((e.y << 16) | (e.z & 0xffff));   // dh = -32768 never in bounds
+    for (int r = 0; r < B_LOADS; ++r) {
+      const int4 e = tab[kb0 + prow + r * 8];
+      te_off[r] = e.x;
+      te_d[r] = e.y >= kInvalid ? (int)0x80000000 : ((e.y << 16) | (e.z & 0xffff));   // dh = -32768 never in bounds
+    }
   }
 
   float ra[A_LOADS], rb[B_LOADS];
@@ -268,41 +320,50 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
   const bool do_sums = (k_tile == 0) && (Psum != nullptr);
   const int zimg = g.M * OHW;                            // dZ image stride
 
-  auto load_tile = [&](int s) {
-    const int pix = p_begin + s * kWgPix + pl;
-    const bool pv = pix < p_end;
-    int n = 0, r = 0, oh = 0, ow = 0;
-    if (pv) {
-      n = pix / OHW;
-      r = pix - n * OHW;
-      oh = r / g.OW;
-      ow = r - oh * g.OW;
-    }
-    const int zbase = n * zimg + r;
-    const int ih0 = oh * g.stride, iw0 = ow * g.stride;
-    const int xbase = n * g.CxHW + ih0 * g.W + iw0;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int m = m0 + prow + i * 8;
-      const bool okm = pv & (m < g.M);
-      const float zv = dZ[okm ? zbase + m * OHW : 0];
-      ra[i] = okm ? zv : 0.f;
-      if (do_sums) rsum[i] += ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int ih = ih0 + (te_d[i] >> 16), iw = iw0 + (int)(short)(te_d[i] & 0xffff);
-      const bool ok = pv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);
-      const float xv = X[ok ? xbase + te_off[i] : 0];
-      rb[i] = ok ? xv : 0.f;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) sA[buf][(prow + i * 8) * kWgPitch + pl] = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) sB[buf][(prow + i * 8) * kWgPitch + pl] = rb[i];
-  };
+  // pixel cursor of this thread (advanced by kWgPix per step)
+  int pix = p_begin + pl;
+  int pn = pix / OHW, prr = pix - pn * OHW;
+  int poh = prr / g.OW, pow_ = prr - poh * g.OW;
+
+#define DASAC_WG_LOAD()                                                                              \
+  {                                                                                                  \
+    const bool pv = pix < p_end;                                                                     \
+    const int zbase = pn * zimg + poh * g.OW + pow_;                                                 \
+    const int ih0 = poh * g.stride, iw0 = pow_ * g.stride;                                           \
+    const int xbase = pn * g.CxHW + ih0 * g.W + iw0;                                                 \
+    if (FAST) {                                                                                      \
+      const unsigned vz = pv ? (unsigned)(zbase + prow * OHW) * 4u : kPoison;                        \
+      _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                          \
+        ra[i] = (m0 + i * 8 < g.M) ? buf_f32(rz, vz, (m0 + i * 8) * OHW * 4) : 0.f;                  \
+        if (do_sums) rsum[i] += ra[i];                                                               \
+      }                                                                                              \
+      const int ih = ih0 + e0.y, iw = iw0 + e0.z;                                                    \
+      const bool ok = pv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);          \
+      const unsigned vx = ok ? (unsigned)(xbase + (e0.x - e0.w) + prow * planeHW) * 4u : kPoison;    \
+      _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) rb[i] = buf_f32(rx, vx, (e0.w + i * 8 * planeHW) * 4); \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                          \
+        const int m = m0 + prow + i * 8;                                                             \
+        ra[i] = buf_f32(rz, (pv & (m < g.M)) ? (unsigned)(zbase + m * OHW) * 4u : kPoison, 0);       \
+        if (do_sums) rsum[i] += ra[i];                                                               \
+      }                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                          \
+        const int ih = ih0 + (te_d[i] >> 16), iw = iw0 + (int)(short)(te_d[i] & 0xffff);             \
+        const bool ok = pv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);        \
+        rb[i] = buf_f32(rx, ok ? (unsigned)(xbase + te_off[i]) * 4u : kPoison, 0);                   \
+      }                                                                                              \
+    }                                                                                                \
+    /* advance the cursor by one step */                                                             \
+    pix += kWgPix;                                                                                   \
+    pow_ += kWgPix;                                                                                  \
+    while (pow_ >= g.OW) { pow_ -= g.OW; ++poh; }                                                    \
+    while (poh >= g.OH) { poh -= g.OH; ++pn; }                                                       \
+  }
+#define DASAC_WG_STORE(buf)                                                                          \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) sA[buf][(prow + i * 8) * kWgPitch + pl] = ra[i]; \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) sB[buf][(prow + i * 8) * kWgPitch + pl] = rb[i]; \
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -313,13 +374,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (steps > 0) {
-    load_tile(0);
-    store_tile(0);
+    DASAC_WG_LOAD();
+    DASAC_WG_STORE(0);
   }
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < steps) load_tile(s + 1);
+    if (s + 1 < steps) DASAC_WG_LOAD();
     const float* a_base = &sA[buf][(wm * WM + li) * kWgPitch + lh];
     const float* b_base = &sB[buf][(wn * WN + li) * kWgPitch + lh];
 #pragma unroll
@@ -334,9 +395,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < steps) store_tile(buf ^ 1);
+    if (s + 1 < steps) DASAC_WG_STORE(buf ^ 1);
     __syncthreads();
   }
+#undef DASAC_WG_LOAD
+#undef DASAC_WG_STORE
 
   if (do_sums) {
     // the 32 lanes of a half-wave hold the 32 pixels of the same rows: butterfly inside the half
@@ -386,7 +449,7 @@ __global__ void build_table(int4* tab, TapGroups tg, int C, int K, int Kpad, int
     }
     const int kh = tap / tg.kw[b], kw = tap - kh * tg.kw[b];
     const int dh = sign * (kh * tg.dil[b] - tg.pad[b]), dw = sign * (kw * tg.dil[b] - tg.pad[b]);
-    e = make_int4(c * planeHW + dh * W + dw, dh, dw, 0);
+    e = make_int4(c * planeHW + dh * W + dw, dh, dw, c * planeHW);
   }
   tab[k] = e;
 }
@@ -456,27 +519,32 @@ static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, 
   DASAC_REQUIRE((int64_t)Nb * Cx * H * W < (1ll << 31) && (int64_t)Nb * M * OutH * OutW < (1ll << 31) &&
                     (int64_t)Nb * OH * OW < (1ll << 31),
                 "conv: tensor exceeds 2^31 elements");
-  DASAC_REQUIRE(Kpad % kBK == 0 && Mpad % 32 == 0 && Mpad >= M, "conv: bad padding Kpad=%d Mpad=%d", Kpad, Mpad);
+  DASAC_REQUIRE(Kpad % 16 == 0 && Mpad % 32 == 0 && Mpad >= M, "conv: bad padding Kpad=%d Mpad=%d", Kpad, Mpad);
   g.H = H; g.W = W; g.CxHW = Cx * H * W; g.OH = OH; g.OW = OW; g.stride = stride; g.Npix = Nb * OH * OW;
   g.M = M; g.Mpad = Mpad; g.Kpad = Kpad; g.OutH = OutH; g.OutW = OutW; g.ostride = ostride;
+  DASAC_REQUIRE((int64_t)Nb * Cx * H * W * 4 < (1ll << 31) && (int64_t)Nb * M * OH * OW * 4 < (1ll << 31),
+                "conv: tensor exceeds the 2 GiB buffer-descriptor window");
+  g.x_bytes = Nb * Cx * H * W * 4;
+  g.z_bytes = Nb * M * OH * OW * 4;
+  g.w_bytes = 0;
   return DASAC_OK;
 }
 
-template <int BM, int BN, int WAVES_M>
+template <int BM, int BN, int WAVES_M, int BK, bool FAST>
 static void launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
                         const Epilogue& ep, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
   const int n_tiles = (g.Npix + BN - 1) / BN;
   const int n_tiles_pad = (n_tiles + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
+  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
                      ep, m_tiles, n_tiles);
 }
 
-template <int BM, int BN, int WAVES_M>
+template <int BM, int BN, int WAVES_M, bool FAST>
 static void launch_wgrad(const float* dZ, const float* X, const int4* tab, float* P, float* Psum, const GemmGeom& g,
                          int splits, int pix_per_split, hipStream_t s) {
   const int m_tiles = g.Mpad / BM, k_tiles = g.Kpad / BN;
-  hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P, Psum,
+  hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P, Psum,
                      g, m_tiles, k_tiles, pix_per_split);
 }
 
@@ -533,13 +601,25 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
   const int Mpad = dasac_conv_mpad(M), Kloop = (K + kBK - 1) / kBK * kBK;   // table/pack are padded to 128 >= Kloop
   int rc = fill_geom(g, Nb, Cx, H, W, OH, OW, stride, M, Mpad, Kloop, OutH, OutW, ostride);
   if (rc) return rc;
+  DASAC_REQUIRE((int64_t)dasac_conv_kpad(K) * Mpad * 4 < (1ll << 31), "conv: packed weights exceed 2 GiB");
+  g.w_bytes = dasac_conv_kpad(K) * Mpad * 4;
   Epilogue ep{scale, shift, res, mask, relu};
   const int4* tab = reinterpret_cast<const int4*>(table);
   hipStream_t s = as_stream(stream);
+  const bool fast = Cx % kBK == 0;      // a K-step never straddles two taps
   switch (pick_bm(Mpad)) {
-    case 128: launch_gemm<128, 128, 2>(x, packed, tab, out, g, ep, s); break;
-    case 64: launch_gemm<64, 128, 2>(x, packed, tab, out, g, ep, s); break;
-    default: launch_gemm<32, 256, 1>(x, packed, tab, out, g, ep, s); break;
+    case 128:
+      if (fast) launch_gemm<128, 128, 2, kBK, true>(x, packed, tab, out, g, ep, s);
+      else launch_gemm<128, 128, 2, kBK, false>(x, packed, tab, out, g, ep, s);
+      break;
+    case 64:
+      if (fast) launch_gemm<64, 128, 2, kBK, true>(x, packed, tab, out, g, ep, s);
+      else launch_gemm<64, 128, 2, kBK, false>(x, packed, tab, out, g, ep, s);
+      break;
+    default:
+      if (fast) launch_gemm<32, 256, 1, kBK, true>(x, packed, tab, out, g, ep, s);
+      else launch_gemm<32, 256, 1, kBK, false>(x, packed, tab, out, g, ep, s);
+      break;
   }
   DASAC_CHECK_LAUNCH("conv_gemm");
   return DASAC_OK;
@@ -577,10 +657,17 @@ extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* 
   float* P = reinterpret_cast<float*>(workspace);
   float* Psum = P + (size_t)splits * Mpad * Kpad;
   hipStream_t s = as_stream(stream);
+  const bool fast = (Cx % 128 == 0) && (M % 8 == 0);   // a 128-row k tile sits inside one tap
   switch (bm) {
-    case 128: launch_wgrad<128, 128, 2>(dz, x, tab, P, Psum, g, splits, per, s); break;
-    case 64: launch_wgrad<64, 128, 2>(dz, x, tab, P, Psum, g, splits, per, s); break;
-    default: launch_wgrad<32, 128, 1>(dz, x, tab, P, Psum, g, splits, per, s); break;
+    case 128:
+      if (fast) launch_wgrad<128, 128, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
+      else launch_wgrad<128, 128, 2, false>(dz, x, tab, P, Psum, g, splits, per, s);
+      break;
+    case 64:
+      if (fast) launch_wgrad<64, 128, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
+      else launch_wgrad<64, 128, 2, false>(dz, x, tab, P, Psum, g, splits, per, s);
+      break;
+    default: launch_wgrad<32, 128, 1, false>(dz, x, tab, P, Psum, g, splits, per, s); break;
   }
   DASAC_CHECK_LAUNCH("conv_wgrad");
   return DASAC_OK;

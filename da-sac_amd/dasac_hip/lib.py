@@ -5,7 +5,7 @@ import os
 
 import torch
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdasac_hip.so")
+LIB_PATH = os.environ.get("DASAC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdasac_hip.so")
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
