@@ -38,12 +38,11 @@ struct GemmGeom {
   int M, Mpad, Kpad;
   // output tensor [Nb, M, OutH, OutW]; element (oh*ostride, ow*ostride)
   int OutH, OutW, ostride;
-  int x_bytes, w_bytes, z_bytes;  // buffer-descriptor extents (gathered tensor, packed weights, dZ)
+  int x_bytes, w_bytes, z_bytes, out_bytes;  // buffer-descriptor extents (gathered tensor, packed weights, dZ, output)
 };
 
 struct Epilogue {
-  const float* scale;   // [M] or null
-  const float* shift;   // [M] or null
+  const float* shift;   // [M] or null (the BN scale is folded into the packed weights)
   const float* res;     // same layout as out, or null  (added before ReLU)
   const float* mask;    // same layout as out, or null  (out = mask>0 ? out : 0, ReLU backward)
   int relu;
@@ -229,36 +228,61 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
 #undef DASAC_LOAD_TILE
 #undef DASAC_STORE_TILE
 
-  // ---- epilogue: BN(eval) scale/shift | bias, residual, ReLU, ReLU-backward mask -----------
+  // ---- epilogue: (+shift | bias) (+residual) (ReLU) (ReLU-backward mask) -> store ----------------
+  // The BN scale is already folded into the packed weights.  All traffic goes through buffer
+  // descriptors: per-lane voffset = pixel position (+ the lane-half's 4-row step), the row offset is
+  // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
   const int OutHW = g.OutH * g.OutW;
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(Out, g.out_bytes);
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(ep.res ? ep.res : Out, g.out_bytes);
+  const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(ep.mask ? ep.mask : Out, g.out_bytes);
+  const __amdgpu_buffer_rsrc_t rsh = make_rsrc(ep.shift ? ep.shift : Out, ep.shift ? g.M * 4 : 0);
+  const bool ragged = (g.M & 7) != 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pix = n0 + wn * WN + j * 32 + li;
-    if (pix >= g.Npix) continue;
-    const int n = pix / OHW, r = pix - n * OHW;
-    const int oh = r / g.OW, ow = r - oh * g.OW;
-    const int obase = n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride;
+    unsigned vo = kPoison;
+    if (pix < g.Npix) {
+      const int n = pix / OHW, r = pix - n * OHW;
+      const int oh = r / g.OW, ow = r - oh * g.OW;
+      vo = (unsigned)(n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHW) * 4u;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int mrow = m0 + wm * WM + i * 32;             // + (rg&3) + 8*(rg>>2) (+4*lh in the lane offset)
+      if (mrow >= g.M) continue;                           // whole 32-row group beyond M (uniform)
+      float sh[16], rs[16], mk[16];
+      unsigned vrow[16];
 #pragma unroll
       for (int rg = 0; rg < 16; ++rg) {
-        const int m = m0 + wm * WM + i * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
-        if (m >= g.M) continue;
-        float v = acc[i][j][rg];
-        if (ep.scale) v = v * ep.scale[m];
-        if (ep.shift) v = v + ep.shift[m];
-        const int idx = obase + m * OutHW;
-        if (ep.res) v = v + ep.res[idx];
+        const int mr = mrow + (rg & 3) + 8 * (rg >> 2);
+        // rows past M: uniform test when M % 8 == 0, per-lane otherwise
+        const bool rowok = ragged ? (mr + 4 * lh < g.M) : (mr < g.M);
+        vrow[rg] = rowok ? vo : kPoison;
+        sh[rg] = ep.shift ? buf_f32(rsh, rowok ? (unsigned)(4 * lh) * 4u : kPoison, mr * 4) : 0.f;
+      }
+      if (ep.res) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) rs[rg] = buf_f32(rres, vrow[rg], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
+      }
+      if (ep.mask) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) mk[rg] = buf_f32(rmsk, vrow[rg], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        float v = acc[i][j][rg] + sh[rg];
+        if (ep.res) v = v + rs[rg];
         if (ep.relu) v = fmaxf(v, 0.f);
-        if (ep.mask) v = ep.mask[idx] > 0.f ? v : 0.f;
-        Out[idx] = v;
+        if (ep.mask) v = mk[rg] > 0.f ? v : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vrow[rg], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4, 0);
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// weight-gradient kernel: reduction over pixels, split across blockIdx.z-like chunks
+// weight-gradient kernel: reduction over pixels, split across blocks
 //   P[split][m][k] = sum_{pix in chunk} dZ[m][pix] * gather(X,k,pix)
 // LDS tiles keep the natural [row][pix] order with an odd row pitch (33) so that both the
 // coalesced tile writes and the strided MFMA operand reads are bank-conflict free.
@@ -454,7 +478,7 @@ __global__ void build_table(int4* tab, TapGroups tg, int C, int K, int Kpad, int
   tab[k] = e;
 }
 
-// mode 0 (forward):  Wp[(tap0+tap)*Cin + ci][co] = W[co][ci][tap]
+// mode 0 (forward):  Wp[(tap0+tap)*Cin + ci][co] = W[co][ci][tap] * (scale ? scale[co] : 1)
 // mode 1 (dgrad):    Wp[(tap0+tap)*Cout + co][ci] = W[co][ci][tap] * (scale ? scale[co] : 1)
 __global__ void pack_weights(const float* __restrict__ Wt, const float* __restrict__ scale, float* __restrict__ Wp,
                              int Cout, int Cin, int taps, int tap0, int Mpad, int mode) {
@@ -466,7 +490,10 @@ __global__ void pack_weights(const float* __restrict__ Wt, const float* __restri
     const int tap = row / C, c = row - tap * C;
     float v = 0.f;
     if (mode == 0) {
-      if (m < Cout) v = Wt[((int64_t)m * Cin + c) * taps + tap];
+      if (m < Cout) {
+        v = Wt[((int64_t)m * Cin + c) * taps + tap];
+        if (scale) v = v * scale[m];
+      }
     } else {
       if (m < Cin) {
         v = Wt[((int64_t)c * Cin + m) * taps + tap];
@@ -524,8 +551,10 @@ static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, 
   g.M = M; g.Mpad = Mpad; g.Kpad = Kpad; g.OutH = OutH; g.OutW = OutW; g.ostride = ostride;
   DASAC_REQUIRE((int64_t)Nb * Cx * H * W * 4 < (1ll << 31) && (int64_t)Nb * M * OH * OW * 4 < (1ll << 31),
                 "conv: tensor exceeds the 2 GiB buffer-descriptor window");
+  DASAC_REQUIRE((int64_t)Nb * M * OutH * OutW * 4 < (1ll << 31), "conv: output exceeds the 2 GiB buffer-descriptor window");
   g.x_bytes = Nb * Cx * H * W * 4;
   g.z_bytes = Nb * M * OH * OW * 4;
+  g.out_bytes = Nb * M * OutH * OutW * 4;
   g.w_bytes = 0;
   return DASAC_OK;
 }
@@ -594,7 +623,7 @@ extern "C" int dasac_conv_pack(const float* w, const float* scale, int Cout, int
 
 extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx,
                                int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
-                               const float* scale, const float* shift, const float* res, const float* mask, int relu,
+                               const float* shift, const float* res, const float* mask, int relu,
                                dasac_stream_t stream) {
   DASAC_REQUIRE(x && packed && table && out, "conv_gemm: null pointer");
   GemmGeom g;
@@ -603,7 +632,7 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
   if (rc) return rc;
   DASAC_REQUIRE((int64_t)dasac_conv_kpad(K) * Mpad * 4 < (1ll << 31), "conv: packed weights exceed 2 GiB");
   g.w_bytes = dasac_conv_kpad(K) * Mpad * 4;
-  Epilogue ep{scale, shift, res, mask, relu};
+  Epilogue ep{shift, res, mask, relu};
   const int4* tab = reinterpret_cast<const int4*>(table);
   hipStream_t s = as_stream(stream);
   const bool fast = Cx % kBK == 0;      // a K-step never straddles two taps

@@ -214,8 +214,8 @@ class Engine:
                 OH, OW = op.spec.out_hw(H, W)
                 scale, shift, _ = self.fold(op)
                 out = torch.empty((Nb, op.spec.cout, OH, OW), dtype=torch.float32, device=xin.device)
-                ops.conv_gemm(xin, self.packed(op, False), self.table(op, H, W, False, xin.device), out, (OH, OW),
-                              op.spec.stride, op.spec.cout, op.spec.K, 1, scale, shift,
+                ops.conv_gemm(xin, self.packed(op, False, scale), self.table(op, H, W, False, xin.device), out, (OH, OW),
+                              op.spec.stride, op.spec.cout, op.spec.K, 1, shift,
                               None if op.res is None else acts[op.res], None, op.relu)
             elif op.kind == "pool":
                 out, arg = ops.maxpool_fwd(xin, op.k, op.s, op.p, op.ceil)
@@ -243,9 +243,10 @@ class Engine:
         return acts[self.plan.output], saved
 
     # ---------------------------------------------------------------- backward
-    def backward(self, saved, grad_out, need):
+    def backward(self, saved, grad_out, need, trace=None):
         """grad_out: gradient w.r.t. the plan output.  need[i]: whether parameter i wants a gradient.
-        Returns the list of parameter gradients (None where not needed)."""
+        Returns the list of parameter gradients (None where not needed).  `trace` (debug): dict that
+        receives the finished activation gradient of every slot."""
         acts, aux = saved["acts"], saved["aux"]
         grads = [None] * len(self.params)
         g = {self.plan.output: grad_out.contiguous()}
@@ -271,6 +272,8 @@ class Engine:
             if dz is None:
                 continue
             assert pending[op.dst] == 0
+            if trace is not None:
+                trace[op.dst] = dz
             xin = acts[op.src]
             if op.kind == "conv":
                 spec = op.spec

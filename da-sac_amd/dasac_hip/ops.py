@@ -134,8 +134,7 @@ def conv_pack(spec, weights, transposed, scale=None, out=None):
     return out
 
 
-def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, scale=None, shift=None, res=None, mask=None,
-              relu=False):
+def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=None, res=None, mask=None, relu=False):
     """out[n,m,oh*os,ow*os] = epilogue(sum_k packed[k][m] * gather(x)); see dasac_conv_gemm."""
     lib = L.load()
     L.require_gpu(x, packed, table, out)
@@ -146,19 +145,19 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, scale=Non
         assert t_ is None or (t_.shape == out.shape and t_.is_contiguous())
     with PROFILE.span("conv_gemm", 2.0 * Nb * OH * OW * M * K):
         L.check(lib.dasac_conv_gemm(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
-                                    stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(scale), L.ptr(shift), L.ptr(res),
+                                    stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
                                     L.ptr(mask), int(relu), L.stream_ptr()), "dasac_conv_gemm")
     return out
 
 
 def conv_forward(spec, x, weights, scale=None, shift=None, res=None, relu=False, table=None, packed=None):
-    """Convenience forward: y = epi(conv(x))."""
+    """Convenience forward: y = relu?(scale*conv(x) + shift + res); `scale` is folded into the packed weights."""
     Nb, _, H, W = x.shape
     OH, OW = spec.out_hw(H, W)
     table = conv_table(spec, H, W, False, x.device) if table is None else table
-    packed = conv_pack(spec, weights, False) if packed is None else packed
+    packed = conv_pack(spec, weights, False, scale) if packed is None else packed
     out = torch.empty((Nb, spec.cout, OH, OW), dtype=torch.float32, device=x.device)
-    return conv_gemm(x, packed, table, out, (OH, OW), spec.stride, spec.cout, spec.K, 1, scale, shift, res, None, relu)
+    return conv_gemm(x, packed, table, out, (OH, OW), spec.stride, spec.cout, spec.K, 1, shift, res, None, relu)
 
 
 def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=None, packed=None):
@@ -169,7 +168,7 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
     packed = conv_pack(spec, weights, True, scale) if packed is None else packed
     if spec.stride == 1:
         dx = torch.empty((Nb, spec.cin, H, W), dtype=torch.float32, device=dz.device)
-        return conv_gemm(dz, packed, table, dx, (H, W), 1, spec.cin, spec.Kt, 1, None, None, res, mask, False)
+        return conv_gemm(dz, packed, table, dx, (H, W), 1, spec.cin, spec.Kt, 1, None, res, mask, False)
     assert spec.taps == 1 and spec.branches[0][3] == 0, "strided data-gradient only for 1x1 convolutions"
     # scatter onto the stride lattice.  Positions off the lattice keep `res` (or 0): the accumulation
     # runs IN PLACE on `res` (each element is read and written by the same thread).
@@ -178,7 +177,7 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
         dx.zero_()
     else:
         dx = res
-    conv_gemm(dz, packed, table, dx, (OH, OW), 1, spec.cin, spec.Kt, spec.stride, None, None,
+    conv_gemm(dz, packed, table, dx, (OH, OW), 1, spec.cin, spec.Kt, spec.stride, None,
               dx if res is not None else None, None, False)
     return relu_mask(dx, mask) if mask is not None else dx
 

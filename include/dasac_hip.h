@@ -63,11 +63,13 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *   K = (sum of kh*kw) * C,  k = tap*C + c (tap-major).
  * dasac_conv_table   builds the gather table [Kpad][4] int32 for planes of plane_h x plane_w;
  *                    transposed=1 gives the data-gradient geometry (C = Cout, dh = pad - kh*dil).
- * dasac_conv_pack    lays W [Cout,Cin,kh,kw] out as [Kpad][Mpad] (transposed=1: rows (tap,co),
- *                    columns ci, optionally scaled per co by `scale` = folded BN gamma*invstd).
+ * dasac_conv_pack    lays W [Cout,Cin,kh,kw] out as the k-interleaved [Kpad/4][Mpad][4] GEMM operand
+ *                    (transposed=1: rows (tap,co), columns ci), optionally scaled per co by
+ *                    `scale` = folded BN gamma*invstd -- forward and data-gradient both contract
+ *                    against scale*W, so the epilogue only adds the shift.
  *                    Call once per branch (tap0 = first tap of the branch, total_taps = all).
  * dasac_conv_gemm    out[n,m,oh*os,ow*os] = epi( sum_k packed[k][m] * x[n, c, oh*stride+dh, ow*stride+dw] )
- *                    epi: v*scale[m] + shift[m] (+res) (ReLU) (zeroed where mask <= 0).
+ *                    epi: v + shift[m] (+res) (ReLU) (zeroed where mask <= 0).
  * dasac_conv_wgrad   partial weight gradients (split over pixels) into `workspace`;
  * dasac_conv_wgrad_finish  sums the splits, writes dW[co,ci,kh,kw] = scale[co]*G and, when `dot`
  *                    is given, dot[co] += sum_k W*G (the frozen-BN gamma gradient term); `sum_dz`
@@ -84,7 +86,7 @@ int dasac_conv_pack(const float* w, const float* scale, int Cout, int Cin, int t
 int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out,
                     int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                     int OutH, int OutW, int ostride,
-                    const float* scale, const float* shift, const float* res, const float* mask,
+                    const float* shift, const float* res, const float* mask,
                     int relu, dasac_stream_t stream);
 size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K);
 int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
