@@ -506,37 +506,41 @@ __global__ void pack_weights(const float* __restrict__ Wt, const float* __restri
 }
 
 // dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G)
-// one block per output channel.
+// grid (chunks of 1024 k, output channels); the dot term is combined with one float atomic per block.
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P, const float* __restrict__ Psum, int splits,
                                                     int Mpad, int Kpad, const float* __restrict__ Wt,
                                                     const float* __restrict__ scale, float* __restrict__ dW,
                                                     float* __restrict__ dot, float* __restrict__ sum_dz, int Cin, int taps,
                                                     int tap0) {
-  const int co = blockIdx.x;
-  if (sum_dz && threadIdx.x == 0) {
+  const int co = blockIdx.y;
+  if (sum_dz && blockIdx.x == 0 && threadIdx.x == 0) {
     float sv = 0.f;
     for (int s = 0; s < splits; ++s) sv += Psum[(size_t)s * Mpad + co];
     sum_dz[co] = sv;
   }
   const int n = Cin * taps;
   const float sc = scale ? scale[co] : 1.f;
+  const size_t slab = (size_t)Mpad * Kpad;
   float part = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    // i runs in the packed order (tap-major) so the slab reads coalesce
-    const int tap = i / Cin, ci = i - tap * Cin;
-    const size_t kidx = (size_t)co * Kpad + (size_t)(tap0 + tap) * Cin + ci;
-    float gsum = 0.f;
-    for (int s = 0; s < splits; ++s) gsum += P[(size_t)s * Mpad * Kpad + kidx];
-    const size_t widx = ((size_t)co * Cin + ci) * taps + tap;
-    if (dot) part += gsum * Wt[widx];
-    dW[widx] = gsum * sc;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = blockIdx.x * 1024 + u * 256 + threadIdx.x;   // packed order (tap-major): coalesced slab reads
+    if (i < n) {
+      const int tap = i / Cin, ci = i - tap * Cin;
+      const size_t kidx = (size_t)co * Kpad + (size_t)(tap0 + tap) * Cin + ci;
+      float gsum = 0.f;
+      for (int s = 0; s < splits; ++s) gsum += P[s * slab + kidx];
+      const size_t widx = ((size_t)co * Cin + ci) * taps + tap;
+      if (dot) part += gsum * Wt[widx];
+      dW[widx] = gsum * sc;
+    }
   }
   if (dot) {
     __shared__ float red[4];
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) dot[co] += red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) atomicAdd(&dot[co], red[0] + red[1] + red[2] + red[3]);
   }
 }
 
@@ -654,13 +658,26 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
   return DASAC_OK;
 }
 
+// Number of pixel splits: every block of a wgrad launch runs for the same time, so pick the split count
+// whose block total fills whole rounds of resident blocks (2 per CU for the 128-row tile, 3 otherwise).
 static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM) {
   const int tiles = (Mpad / BM) * (Kpad / 128);
-  int splits = (kNumCu * 4 + tiles - 1) / tiles;            // aim at >= 4 blocks per CU
-  const int max_splits = (Npix + 1023) / 1024;              // at least 1024 pixels per split
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  return splits;
+  const int slots = kNumCu * (BM == 128 ? 2 : 3);
+  int max_splits = (Npix + 1023) / 1024;                    // at least 1024 pixels per split
+  if (max_splits > 64) max_splits = 64;
+  if (max_splits < 1) max_splits = 1;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const int blocks = tiles * sp;
+    const int rounds = (blocks + slots - 1) / slots;
+    const double eff = (double)blocks / ((double)rounds * slots);
+    if (eff > best_eff + 0.02) {                             // prefer fewer splits unless clearly better
+      best_eff = eff;
+      best = sp;
+    }
+  }
+  return best;
 }
 
 extern "C" size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K) {
@@ -709,8 +726,8 @@ extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, in
   const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
   const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
   const float* P = reinterpret_cast<const float*>(workspace);
-  hipLaunchKernelGGL(wgrad_reduce, dim3(M), dim3(256), 0, as_stream(stream), P, P + (size_t)splits * Mpad * Kpad, splits, Mpad,
-                     Kpad, w, scale, dw, dot, sum_dz, Cin, taps, tap0);
+  hipLaunchKernelGGL(wgrad_reduce, dim3((Cin * taps + 1023) / 1024, M), dim3(256), 0, as_stream(stream), P,
+                     P + (size_t)splits * Mpad * Kpad, splits, Mpad, Kpad, w, scale, dw, dot, sum_dz, Cin, taps, tap0);
   DASAC_CHECK_LAUNCH("wgrad_reduce");
   return DASAC_OK;
 }
