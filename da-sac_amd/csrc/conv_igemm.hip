@@ -81,10 +81,17 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // FAST: the gathered tensor's channel count is a multiple of BK, so a K-step never straddles two
 // taps: one (dh, dw) per step, validity and the spatial offset computed once per thread and step, the
 // channel offset of each row rides in the scalar operand (zero VALU per gathered element).
-template <int BM, int BN, int WAVES_M, int BK, bool FAST>
-__global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
+// STREAMK: persistent launch (3 workers per CU).  The (tile, K-step) iteration space is cut into equal
+// contiguous ranges, one per worker, so every CU gets the same amount of matrix work no matter how the
+// tile count divides by the CU count (1178 tiles on 256 CUs would otherwise run 5 "rounds" for 4.6 of
+// work).  A tile cut by a range boundary is finished by the worker holding its FIRST K-steps (it reaches
+// them last); the other worker deposits its accumulators in `partial` as soon as it has them and raises
+// a flag (agent-scope release/acquire, placement independent).
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK>
+__global__ __launch_bounds__(kThreads, STREAMK ? 2 : 3) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
-                                                      GemmGeom g, Epilogue ep, int m_tiles, int n_tiles) {
+                                                      GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
+                                                      float* __restrict__ partial, int* __restrict__ flags) {
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -93,59 +100,89 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
   constexpr int A_PER_T = (A_VEC + kThreads - 1) / kThreads;
   constexpr int B_Q_PASS = kThreads / BN > 0 ? kThreads / BN : 1;   // k quads covered by one pass of the block
   constexpr int B_QUADS = KQ / B_Q_PASS;                     // quads (of 4 rows) gathered per thread
+  constexpr int ACC_REGS = TM * TN * 16;
   static_assert(TM >= 1 && TN >= 1 && BN <= kThreads && KQ % B_Q_PASS == 0, "tile shape");
 
   __shared__ f32x4 sA[2][KQ * BM];
   __shared__ f32x4 sB[2][KQ * BN];
 
-  // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole pixel tiles so that the M
-  // tiles sharing an activation tile hit the same L2.
-  const int bid = blockIdx.x;
-  const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
-  const int n_tile = (slot / m_tiles) * kNumXcd + xcd;
-  const int m_tile = slot % m_tiles;
-  if (n_tile >= n_tiles) return;
-  const int m0 = m_tile * BM, n0 = n_tile * BN;
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform on purpose: scalar buffer offsets
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(X, g.x_bytes);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(Wp, g.w_bytes);
 
-  // ---- this thread's pixel column of the gather ---------------------------------------------
   const int OHW = g.OH * g.OW;
   const int planeHW = g.H * g.W;
   const int bcol = t % BN;
   const int bq0 = __builtin_amdgcn_readfirstlane(t / BN);    // wave-uniform first quad
-  int pixbase, ih0, iw0;
-  {
-    const int pix = n0 + bcol;
-    if (pix < g.Npix) {
-      const int n = pix / OHW, r = pix - n * OHW;
-      const int oh = r / g.OW, ow = r - oh * g.OW;
-      ih0 = oh * g.stride;
-      iw0 = ow * g.stride;
-      pixbase = n * g.CxHW + ih0 * g.W + iw0;
-    } else {
-      ih0 = -kInvalid;     // every tap out of bounds -> poison offsets -> zeros
-      iw0 = 0;
-      pixbase = 0;
-    }
-  }
-  // weight tile: per-thread byte offsets inside a K-step, the K-step itself goes in the scalar offset
-  unsigned voff_a[A_PER_T];
-#pragma unroll
-  for (int i = 0; i < A_PER_T; ++i) {
-    const int v = t + i * kThreads;
-    const int q = v / BM, m = v - q * BM;
-    voff_a[i] = (unsigned)(q * g.Mpad + m0 + m) * 16u;
-  }
   const int a_step_bytes = KQ * g.Mpad * 16;
+  const int KT = g.Kpad / BK;
+  const int OutHW = g.OutH * g.OutW;
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(Out, g.out_bytes);
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(ep.res ? ep.res : Out, g.out_bytes);
+  const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(ep.mask ? ep.mask : Out, g.out_bytes);
+  const __amdgpu_buffer_rsrc_t rsh = make_rsrc(ep.shift ? ep.shift : Out, ep.shift ? g.M * 4 : 0);
+  const bool ragged = (g.M & 7) != 0;
+  const __amdgpu_buffer_rsrc_t rpart = make_rsrc(STREAMK ? (const void*)partial : (const void*)Out,
+                                                 STREAMK ? (int)gridDim.x * ACC_REGS * kThreads * 4 : 0);
 
-  f32x4 ra[A_PER_T];
-  f32x4 rb[B_QUADS];
+  // ---- which part of the iteration space is mine --------------------------------------------
+  // block b runs on XCD b%8: tiles (or ranges) that are adjacent -- same activation tile, next M tile --
+  // go to the same XCD so that they share its L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
+  long long it, it_end;
+  int my_range = 0;
+  if (STREAMK) {
+    const int G = gridDim.x;                                 // multiple of 8
+    my_range = xcd * (G / kNumXcd) + slot;
+    const long long total = (long long)m_tiles * n_tiles * KT;
+    it = total * my_range / G;
+    it_end = total * (my_range + 1) / G;
+  } else {
+    const int n_tile = (slot / m_tiles) * kNumXcd + xcd;
+    if (n_tile >= n_tiles) return;
+    it = ((long long)n_tile * m_tiles + slot % m_tiles) * KT;
+    it_end = it + KT;
+  }
+
+  while (it < it_end) {
+    const int tile = (int)(it / KT);
+    const int ks = (int)(it - (long long)tile * KT);
+    const int ke = (int)min((long long)KT, ks + (it_end - it));
+    it += ke - ks;
+    const int m0 = (tile % m_tiles) * BM, n0 = (tile / m_tiles) * BN;
+
+    // ---- this thread's pixel column of the gather -------------------------------------------
+    int pixbase, ih0, iw0;
+    {
+      const int pix = n0 + bcol;
+      if (pix < g.Npix) {
+        const int n = pix / OHW, r = pix - n * OHW;
+        const int oh = r / g.OW, ow = r - oh * g.OW;
+        ih0 = oh * g.stride;
+        iw0 = ow * g.stride;
+        pixbase = n * g.CxHW + ih0 * g.W + iw0;
+      } else {
+        ih0 = -kInvalid;     // every tap out of bounds -> poison offsets -> zeros
+        iw0 = 0;
+        pixbase = 0;
+      }
+    }
+    // weight tile: per-thread byte offsets inside a K-step, the K-step itself goes in the scalar offset
+    unsigned voff_a[A_PER_T];
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int v = t + i * kThreads;
+      const int q = v / BM, m = v - q * BM;
+      voff_a[i] = (unsigned)(q * g.Mpad + m0 + m) * 16u;
+    }
+
+    f32x4 ra[A_PER_T];
+    f32x4 rb[B_QUADS];
 
 #define DASAC_LOAD_TILE(kt)                                                                          \
   {                                                                                                  \
@@ -185,99 +222,155 @@ __global__ __launch_bounds__(kThreads) void conv_gemm(const float* __restrict__ 
     _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) sB[buf][(bq0 + r * B_Q_PASS) * BN + bcol] = rb[r]; \
   }
 
-  f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = g.Kpad / BK;
-  DASAC_LOAD_TILE(0);
-  DASAC_STORE_TILE(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) DASAC_LOAD_TILE(kt + 1);
-    f32x4 a4[BK / 8][TM], b4[BK / 8][TN];
-#pragma unroll
-    for (int gq = 0; gq < BK / 8; ++gq) {
-      const int q = 2 * gq + lh;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a4[gq][i] = sA[buf][q * BM + wm * WM + i * 32 + li];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b4[gq][j] = sB[buf][q * BN + wn * WN + j * 32 + li];
-    }
-#pragma unroll
-    for (int gq = 0; gq < BK / 8; ++gq) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].x, b4[gq][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].y, b4[gq][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].z, b4[gq][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].w, b4[gq][j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (more) DASAC_STORE_TILE(buf ^ 1);
+    DASAC_LOAD_TILE(ks);
+    DASAC_STORE_TILE(ks & 1);
     __syncthreads();
-  }
+    for (int kt = ks; kt < ke; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < ke;
+      if (more) DASAC_LOAD_TILE(kt + 1);
+      f32x4 a4[BK / 8][TM], b4[BK / 8][TN];
+#pragma unroll
+      for (int gq = 0; gq < BK / 8; ++gq) {
+        const int q = 2 * gq + lh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a4[gq][i] = sA[buf][q * BM + wm * WM + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b4[gq][j] = sB[buf][q * BN + wn * WN + j * 32 + li];
+      }
+#pragma unroll
+      for (int gq = 0; gq < BK / 8; ++gq) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].x, b4[gq][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].y, b4[gq][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].z, b4[gq][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].w, b4[gq][j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      if (more) DASAC_STORE_TILE(buf ^ 1);
+      __syncthreads();
+    }
 #undef DASAC_LOAD_TILE
 #undef DASAC_STORE_TILE
 
-  // ---- epilogue: (+shift | bias) (+residual) (ReLU) (ReLU-backward mask) -> store ----------------
-  // The BN scale is already folded into the packed weights.  All traffic goes through buffer
-  // descriptors: per-lane voffset = pixel position (+ the lane-half's 4-row step), the row offset is
-  // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
-  const int OutHW = g.OutH * g.OutW;
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc(Out, g.out_bytes);
-  const __amdgpu_buffer_rsrc_t rres = make_rsrc(ep.res ? ep.res : Out, g.out_bytes);
-  const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(ep.mask ? ep.mask : Out, g.out_bytes);
-  const __amdgpu_buffer_rsrc_t rsh = make_rsrc(ep.shift ? ep.shift : Out, ep.shift ? g.M * 4 : 0);
-  const bool ragged = (g.M & 7) != 0;
+    if (STREAMK) {
+      if (ks > 0) {
+        // I hold the LAST K-steps of a tile that starts in the previous range: deposit and move on.
+        const int dst0 = my_range * (ACC_REGS * kThreads * 4);     // bytes; scalar
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int pix = n0 + wn * WN + j * 32 + li;
-    unsigned vo = kPoison;
-    if (pix < g.Npix) {
-      const int n = pix / OHW, r = pix - n * OHW;
-      const int oh = r / g.OW, ow = r - oh * g.OW;
-      vo = (unsigned)(n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHW) * 4u;
-    }
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mrow = m0 + wm * WM + i * 32;             // + (rg&3) + 8*(rg>>2) (+4*lh in the lane offset)
-      if (mrow >= g.M) continue;                           // whole 32-row group beyond M (uniform)
-      float sh[16], rs[16], mk[16];
-      unsigned vrow[16];
+          for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        const int mr = mrow + (rg & 3) + 8 * (rg >> 2);
-        // rows past M: uniform test when M % 8 == 0, per-lane otherwise
-        const bool rowok = ragged ? (mr + 4 * lh < g.M) : (mr < g.M);
-        vrow[rg] = rowok ? vo : kPoison;
-        sh[rg] = ep.shift ? buf_f32(rsh, rowok ? (unsigned)(4 * lh) * 4u : kPoison, mr * 4) : 0.f;
+            for (int r = 0; r < 16; ++r)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rpart, (unsigned)t * 4u,
+                                                    dst0 + ((i * TN + j) * 16 + r) * kThreads * 4, 0);
+            asm volatile("" ::: "memory");
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(&flags[my_range], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        continue;
       }
-      if (ep.res) {
+      if (ke < KT) {
+        // I hold the FIRST K-steps; the rest was deposited by the next range at the start of its work.
+        if (t == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(&flags[my_range + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1 << 26)) {
+            __builtin_amdgcn_s_sleep(8);
+            ++spins;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const int src0 = (my_range + 1) * (ACC_REGS * kThreads * 4);
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) rs[rg] = buf_f32(rres, vrow[rg], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
-      }
-      if (ep.mask) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) mk[rg] = buf_f32(rmsk, vrow[rg], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
-      }
+          for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        float v = acc[i][j][rg] + sh[rg];
-        if (ep.res) v = v + rs[rg];
-        if (ep.relu) v = fmaxf(v, 0.f);
-        if (ep.mask) v = mk[rg] > 0.f ? v : 0.f;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vrow[rg], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4, 0);
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] += buf_f32(rpart, (unsigned)t * 4u, src0 + ((i * TN + j) * 16 + r) * kThreads * 4);
+            asm volatile("" ::: "memory");
+          }
       }
     }
+
+    // ---- epilogue: (+shift | bias) (+residual) (ReLU) (ReLU-backward mask) -> store ----------------
+    // The BN scale is already folded into the packed weights.  All traffic goes through buffer
+    // descriptors: per-lane voffset = pixel position (+ the lane-half's 4-row step), the row offset is
+    // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int pix = n0 + wn * WN + j * 32 + li;
+      unsigned vo = kPoison;
+      if (pix < g.Npix) {
+        const int n = pix / OHW, r = pix - n * OHW;
+        const int oh = r / g.OW, ow = r - oh * g.OW;
+        vo = (unsigned)(n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHW) * 4u;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mrow = m0 + wm * WM + i * 32;             // + (rg&3) + 8*(rg>>2) (+4*lh in the lane offset)
+        if (mrow >= g.M) continue;                           // whole 32-row group beyond M (uniform)
+        // 8 rows at a time: one batch of loads (shift, residual, mask), then the arithmetic and the stores;
+        // the compiler barrier keeps the batches from being merged (register pressure -> occupancy).
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float sh[8], rs[8], mk[8];
+          unsigned vrow[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int rg = half * 8 + u;
+            const int mr = mrow + (rg & 3) + 8 * (rg >> 2);
+            // rows past M: uniform test when M % 8 == 0, per-lane otherwise
+            const bool rowok = ragged ? (mr + 4 * lh < g.M) : (mr < g.M);
+            vrow[u] = rowok ? vo : kPoison;
+            sh[u] = ep.shift ? buf_f32(rsh, rowok ? (unsigned)(4 * lh) * 4u : kPoison, mr * 4) : 0.f;
+          }
+          if (ep.res) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int rg = half * 8 + u;
+              rs[u] = buf_f32(rres, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
+            }
+          }
+          if (ep.mask) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int rg = half * 8 + u;
+              mk[u] = buf_f32(rmsk, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int rg = half * 8 + u;
+            float v = acc[i][j][rg] + sh[u];
+            if (ep.res) v = v + rs[u];
+            if (ep.relu) v = fmaxf(v, 0.f);
+            if (ep.mask) v = mk[u] > 0.f ? v : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4, 0);
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+    if (STREAMK) __syncthreads();      // LDS is reused by the next tile of this worker
   }
 }
 
@@ -309,7 +402,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
   const int tile = blockIdx.x % (m_tiles * k_tiles), split = blockIdx.x / (m_tiles * k_tiles);
   const int m_tile = tile % m_tiles, k_tile = tile / m_tiles;
   const int m0 = m_tile * BM, kb0 = k_tile * BN;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform on purpose: scalar buffer offsets
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
   const int pl = t & 31, prow = t >> 5;                  // loader: pixel lane, row within pass
@@ -563,14 +657,42 @@ static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, 
   return DASAC_OK;
 }
 
+constexpr int kSkWorkersPerCu = 2;                       // persistent 128x128 workers per CU
+constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 512, multiple of 8
+
+// stream-K pays when the tile count leaves the last round of resident blocks (3 per CU for the plain
+// kernel) mostly empty
+static bool want_streamk(int tiles, int k_steps) {
+  static const int mode = getenv("DASAC_STREAMK") ? atoi(getenv("DASAC_STREAMK")) : 1;   // 0 off, 1 auto, 2 always
+  if (mode == 0 || tiles < kSkWorkers) return false;
+  if (mode == 2) return true;
+  // measured: the persistent schedule (2 workers/CU) wins on long contractions whose tile count fills the
+  // last round of the plain launch badly; short-K 1x1 layers are better off with 3 plain blocks per CU.
+  const int resident = kNumCu * 3;
+  const int rounds = (tiles + resident - 1) / resident;
+  return k_steps >= 64 && (double)tiles / ((double)rounds * resident) < 0.93;
+}
+
 template <int BM, int BN, int WAVES_M, int BK, bool FAST>
-static void launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
-                        const Epilogue& ep, hipStream_t s) {
+static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
+                       const Epilogue& ep, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
   const int n_tiles = (g.Npix + BN - 1) / BN;
+  if (BM == 128 && workspace && want_streamk(m_tiles * n_tiles, g.Kpad / BK)) {
+    const size_t part_bytes = (size_t)kSkWorkers * (BM * BN) * sizeof(float);
+    const size_t need = part_bytes + (size_t)(kSkWorkers + 1) * sizeof(int);
+    if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
+    float* partial = reinterpret_cast<float*>(workspace);
+    int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
+    DASAC_HIP(hipMemsetAsync(flags, 0, (size_t)(kSkWorkers + 1) * sizeof(int), s));
+    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g, ep,
+                       m_tiles, n_tiles, partial, flags);
+    return DASAC_OK;
+  }
   const int n_tiles_pad = (n_tiles + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
-                     ep, m_tiles, n_tiles);
+  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab,
+                     Out, g, ep, m_tiles, n_tiles, nullptr, nullptr);
+  return DASAC_OK;
 }
 
 template <int BM, int BN, int WAVES_M, bool FAST>
@@ -625,10 +747,14 @@ extern "C" int dasac_conv_pack(const float* w, const float* scale, int Cout, int
   return DASAC_OK;
 }
 
+extern "C" size_t dasac_conv_gemm_workspace(void) {
+  return (size_t)kSkWorkers * 128 * 128 * sizeof(float) + (size_t)(kSkWorkers + 1) * sizeof(int);
+}
+
 extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx,
                                int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
                                const float* shift, const float* res, const float* mask, int relu,
-                               dasac_stream_t stream) {
+                               void* workspace, size_t ws_bytes, dasac_stream_t stream) {
   DASAC_REQUIRE(x && packed && table && out, "conv_gemm: null pointer");
   GemmGeom g;
   const int Mpad = dasac_conv_mpad(M), Kloop = (K + kBK - 1) / kBK * kBK;   // table/pack are padded to 128 >= Kloop
@@ -642,18 +768,19 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
   const bool fast = Cx % kBK == 0;      // a K-step never straddles two taps
   switch (pick_bm(Mpad)) {
     case 128:
-      if (fast) launch_gemm<128, 128, 2, kBK, true>(x, packed, tab, out, g, ep, s);
-      else launch_gemm<128, 128, 2, kBK, false>(x, packed, tab, out, g, ep, s);
+      rc = fast ? launch_gemm<128, 128, 2, kBK, true>(x, packed, tab, out, g, ep, workspace, ws_bytes, s)
+                : launch_gemm<128, 128, 2, kBK, false>(x, packed, tab, out, g, ep, workspace, ws_bytes, s);
       break;
     case 64:
-      if (fast) launch_gemm<64, 128, 2, kBK, true>(x, packed, tab, out, g, ep, s);
-      else launch_gemm<64, 128, 2, kBK, false>(x, packed, tab, out, g, ep, s);
+      rc = fast ? launch_gemm<64, 128, 2, kBK, true>(x, packed, tab, out, g, ep, nullptr, 0, s)
+                : launch_gemm<64, 128, 2, kBK, false>(x, packed, tab, out, g, ep, nullptr, 0, s);
       break;
     default:
-      if (fast) launch_gemm<32, 256, 1, kBK, true>(x, packed, tab, out, g, ep, s);
-      else launch_gemm<32, 256, 1, kBK, false>(x, packed, tab, out, g, ep, s);
+      rc = fast ? launch_gemm<32, 256, 1, kBK, true>(x, packed, tab, out, g, ep, nullptr, 0, s)
+                : launch_gemm<32, 256, 1, kBK, false>(x, packed, tab, out, g, ep, nullptr, 0, s);
       break;
   }
+  if (rc) return rc;
   DASAC_CHECK_LAUNCH("conv_gemm");
   return DASAC_OK;
 }

@@ -1,4 +1,6 @@
 """Tensor-level wrappers over the C ABI (one function per kernel family)."""
+import os
+
 import torch
 
 from . import lib as L
@@ -143,10 +145,12 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     assert out.shape[0] == Nb and out.shape[1] == M and x.is_contiguous() and out.is_contiguous()
     for t_ in (res, mask):
         assert t_ is None or (t_.shape == out.shape and t_.is_contiguous())
+    ws = L.workspace(lib.dasac_conv_gemm_workspace(), x.device)
     with PROFILE.span("conv_gemm", 2.0 * Nb * OH * OW * M * K):
         L.check(lib.dasac_conv_gemm(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
                                     stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
-                                    L.ptr(mask), int(relu), L.stream_ptr()), "dasac_conv_gemm")
+                                    L.ptr(mask), int(relu), L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr()),
+                "dasac_conv_gemm")
     return out
 
 

@@ -69,7 +69,9 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *                    against scale*W, so the epilogue only adds the shift.
  *                    Call once per branch (tap0 = first tap of the branch, total_taps = all).
  * dasac_conv_gemm    out[n,m,oh*os,ow*os] = epi( sum_k packed[k][m] * x[n, c, oh*stride+dh, ow*stride+dw] )
- *                    epi: v + shift[m] (+res) (ReLU) (zeroed where mask <= 0).
+ *                    epi: v + shift[m] (+res) (ReLU) (zeroed where mask <= 0).  With a workspace of
+ *                    dasac_conv_gemm_workspace() bytes the launcher may pick the persistent stream-K
+ *                    schedule (equal matrix work per CU); workspace NULL = one block per tile.
  * dasac_conv_wgrad   partial weight gradients (split over pixels) into `workspace`;
  * dasac_conv_wgrad_finish  sums the splits, writes dW[co,ci,kh,kw] = scale[co]*G and, when `dot`
  *                    is given, dot[co] += sum_k W*G (the frozen-BN gamma gradient term); `sum_dz`
@@ -87,7 +89,8 @@ int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, f
                     int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                     int OutH, int OutW, int ostride,
                     const float* shift, const float* res, const float* mask,
-                    int relu, dasac_stream_t stream);
+                    int relu, void* workspace, size_t ws_bytes, dasac_stream_t stream);
+size_t dasac_conv_gemm_workspace(void);
 size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K);
 int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
                      int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
