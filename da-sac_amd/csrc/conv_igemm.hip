@@ -747,6 +747,14 @@ extern "C" int dasac_conv_pack(const float* w, const float* scale, int Cout, int
   return DASAC_OK;
 }
 
+// 1 when dasac_conv_gemm (given a workspace) runs this shape on the persistent stream-K schedule
+extern "C" int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K) {
+  const int Mpad = dasac_conv_mpad(M);
+  if (pick_bm(Mpad) != 128) return 0;
+  const int tiles = ((M + 127) / 128) * ((Nb * OH * OW + 127) / 128);
+  return want_streamk(tiles, (K + kBK - 1) / kBK) ? 1 : 0;
+}
+
 extern "C" size_t dasac_conv_gemm_workspace(void) {
   return (size_t)kSkWorkers * 128 * 128 * sizeof(float) + (size_t)(kSkWorkers + 1) * sizeof(int);
 }

@@ -146,7 +146,10 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     for t_ in (res, mask):
         assert t_ is None or (t_.shape == out.shape and t_.is_contiguous())
     ws = L.workspace(lib.dasac_conv_gemm_workspace(), x.device)
-    with PROFILE.span("conv_gemm", 2.0 * Nb * OH * OW * M * K):
+    span = "conv_gemm"
+    if PROFILE.on:
+        span = "conv_gemm<stream-K>" if lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K) else "conv_gemm<tile-per-block>"
+    with PROFILE.span(span, 2.0 * Nb * OH * OW * M * K):
         L.check(lib.dasac_conv_gemm(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
                                     stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
                                     L.ptr(mask), int(relu), L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr()),

@@ -91,6 +91,7 @@ int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, f
                     const float* shift, const float* res, const float* mask,
                     int relu, void* workspace, size_t ws_bytes, dasac_stream_t stream);
 size_t dasac_conv_gemm_workspace(void);
+int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K);   /* 1 = stream-K, 0 = one block per tile */
 size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K);
 int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
                      int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
