@@ -265,3 +265,182 @@ extern "C" int dasac_relu_mask(const float* dy, const float* y, float* out, int6
   DASAC_CHECK_LAUNCH("relu_mask");
   return DASAC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Train-mode BatchNorm (baseline / AdaBN mode: models/__init__.py:29 leaves BN un-frozen, every
+// nn.SyncBatchNorm of deeplabv2.py:15 / fcn.py:8 normalises with batch statistics; train.py:281-289
+// re-estimates the running statistics on target crops).  Cross-rank statistics (SyncBN) are summed by
+// the caller with one RCCL all-reduce of the raw (sum, sum of squares) / (sum dy, sum dy*xhat) vectors.
+// ------------------------------------------------------------------------------------------------
+namespace dasac {
+
+constexpr int kBnChunk = 256 * 16;
+
+// sums[c] += sum z, sums[C + c] += sum z^2   (double atomics, grid = (chunks, N*C planes))
+__global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int C, int HW, double* __restrict__ sums) {
+  const int plane = blockIdx.y, c = plane % C;
+  const float* p = z + (size_t)plane * HW;
+  double s = 0, q = 0;
+  for (int i = blockIdx.x * kBnChunk + threadIdx.x; i < min(HW, (int)(blockIdx.x + 1) * kBnChunk); i += 256) {
+    const double v = p[i];
+    s += v;
+    q += v * v;
+  }
+  __shared__ double rs[4], rq[4];
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) {
+    rs[threadIdx.x >> 6] = s;
+    rq[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[c], rs[0] + rs[1] + rs[2] + rs[3]);
+    atomicAdd(&sums[C + c], rq[0] + rq[1] + rq[2] + rq[3]);
+  }
+}
+
+// batch mean / biased var -> scale, shift, mean, invstd; running stats: momentum update with the unbiased var
+__global__ void bn_train_finalize(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ running_mean,
+                                  float* __restrict__ running_var, float momentum, float eps, int C,
+                                  float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                  float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / count;
+  double var = sums[C + c] / count - m * m;
+  if (var < 0) var = 0;
+  const float meanf = (float)m, varf = (float)var;
+  const float is = 1.f / sqrtf(varf + eps);
+  const float a = gamma[c] * is;
+  scale[c] = a;
+  shift[c] = beta[c] - meanf * a;
+  mean_out[c] = meanf;
+  invstd_out[c] = is;
+  if (running_mean) {
+    const float unbiased = count > 1 ? (float)(var * count / (count - 1)) : varf;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// y = relu?(z*scale[c] + shift[c] (+res))
+__global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ z, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, const float* __restrict__ res, int relu,
+                                                int C, int HW, float* __restrict__ y, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    float v = z[i] * scale[c] + shift[c];
+    if (res) v += res[i];
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+  }
+}
+
+// sums[c] += sum dy, sums[C + c] += sum dy * xhat,  xhat = (z - mean)*invstd
+__global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd, int C,
+                                                     int HW, double* __restrict__ sums) {
+  const int plane = blockIdx.y, c = plane % C;
+  const float* pd = dy + (size_t)plane * HW;
+  const float* pz = z + (size_t)plane * HW;
+  const float m = mean[c], is = invstd[c];
+  double s = 0, q = 0;
+  for (int i = blockIdx.x * kBnChunk + threadIdx.x; i < min(HW, (int)(blockIdx.x + 1) * kBnChunk); i += 256) {
+    const float d = pd[i];
+    s += d;
+    q += (double)d * (double)((pz[i] - m) * is);
+  }
+  __shared__ double rs[4], rq[4];
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) {
+    rs[threadIdx.x >> 6] = s;
+    rq[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[c], rs[0] + rs[1] + rs[2] + rs[3]);
+    atomicAdd(&sums[C + c], rq[0] + rq[1] + rq[2] + rq[3]);
+  }
+}
+
+// dz = gamma*invstd * (dy - sum_dy/n - xhat * sum_dy_xhat/n);  dgamma = sum_dy_xhat, dbeta = sum_dy
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ z,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                    double count, int C, int HW, float* __restrict__ dz, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    const float is = invstd[c];
+    const float xh = (z[i] - mean[c]) * is;
+    const float a = (float)(sums[c] / count), b = (float)(sums[C + c] / count);
+    dz[i] = gamma[c] * is * (dy[i] - a - xh * b);
+  }
+}
+
+__global__ void bn_bwd_params(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] = (float)sums[c];
+  if (dgamma) dgamma[c] = (float)sums[C + c];
+}
+
+}  // namespace dasac
+
+extern "C" int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, dasac_stream_t stream) {
+  DASAC_REQUIRE(z && sums && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31), "bn_stats: bad arguments");
+  hipStream_t s = as_stream(stream);
+  DASAC_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), s));
+  hipLaunchKernelGGL(bn_stats, dim3((unsigned)((HW + kBnChunk - 1) / kBnChunk), N * C), dim3(256), 0, s, z, C, (int)HW, sums);
+  DASAC_CHECK_LAUNCH("bn_stats");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_train_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps, int C,
+                                       float* scale, float* shift, float* mean, float* invstd, dasac_stream_t stream) {
+  DASAC_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0, "bn_train_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_train_finalize, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd);
+  DASAC_CHECK_LAUNCH("bn_train_finalize");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu, int N,
+                              int C, int64_t HW, float* y, dasac_stream_t stream) {
+  DASAC_REQUIRE(z && scale && shift && y && N > 0 && C > 0 && HW > 0, "bn_apply: bad arguments");
+  const int64_t total = (int64_t)N * C * HW;
+  hipLaunchKernelGGL(bn_apply, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), z, scale, shift, res, relu, C,
+                     (int)HW, y, total);
+  DASAC_CHECK_LAUNCH("bn_apply");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd, int N, int C,
+                                   int64_t HW, double* sums, dasac_stream_t stream) {
+  DASAC_REQUIRE(dy && z && mean && invstd && sums && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31), "bn_bwd_reduce: bad arguments");
+  hipStream_t s = as_stream(stream);
+  DASAC_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), s));
+  hipLaunchKernelGGL(bn_bwd_reduce, dim3((unsigned)((HW + kBnChunk - 1) / kBnChunk), N * C), dim3(256), 0, s, dy, z, mean, invstd,
+                     C, (int)HW, sums);
+  DASAC_CHECK_LAUNCH("bn_bwd_reduce");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const float* invstd,
+                                  const float* gamma, const double* sums, double count, int N, int C, int64_t HW, float* dz,
+                                  float* dgamma, float* dbeta, dasac_stream_t stream) {
+  DASAC_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && count > 0, "bn_bwd_apply: bad arguments");
+  const int64_t total = (int64_t)N * C * HW;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, z, mean, invstd, gamma, sums, count, C,
+                     (int)HW, dz, total);
+  DASAC_CHECK_LAUNCH("bn_bwd_apply");
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(bn_bwd_params, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma, dbeta);
+    DASAC_CHECK_LAUNCH("bn_bwd_params");
+  }
+  return DASAC_OK;
+}

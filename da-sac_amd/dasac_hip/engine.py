@@ -212,11 +212,21 @@ class Engine:
             if op.kind == "conv":
                 Nb, _, H, W = xin.shape
                 OH, OW = op.spec.out_hw(H, W)
-                scale, shift, _ = self.fold(op)
                 out = torch.empty((Nb, op.spec.cout, OH, OW), dtype=torch.float32, device=xin.device)
-                ops.conv_gemm(xin, self.packed(op, False, scale), self.table(op, H, W, False, xin.device), out, (OH, OW),
-                              op.spec.stride, op.spec.cout, op.spec.K, 1, shift,
-                              None if op.res is None else acts[op.res], None, op.relu)
+                if op.bn is not None and op.bn.training:
+                    # batch-statistics BN (baseline / AdaBN mode): raw conv, then stats -> normalise(+res)(+ReLU)
+                    cb = op.convs[0].bias.detach() if op.has_bias else None
+                    ops.conv_gemm(xin, self.packed(op, False, None), self.table(op, H, W, False, xin.device), out, (OH, OW),
+                                  op.spec.stride, op.spec.cout, op.spec.K, 1, cb, None, None, False)
+                    z = out
+                    out, stats = ops.bn_train_forward(z, op.bn, None if op.res is None else acts[op.res], op.relu)
+                    if keep:
+                        saved["aux"][i] = (z, stats)
+                else:
+                    scale, shift, _ = self.fold(op)
+                    ops.conv_gemm(xin, self.packed(op, False, scale), self.table(op, H, W, False, xin.device), out, (OH, OW),
+                                  op.spec.stride, op.spec.cout, op.spec.K, 1, shift,
+                                  None if op.res is None else acts[op.res], None, op.relu)
             elif op.kind == "pool":
                 out, arg = ops.maxpool_fwd(xin, op.k, op.s, op.p, op.ceil)
                 if keep:
@@ -278,14 +288,25 @@ class Engine:
             if op.kind == "conv":
                 spec = op.spec
                 Nb, _, H, W = xin.shape
-                scale, shift, invstd = self.fold(op)
+                dy_out = dz                       # gradient w.r.t. the op output (what a residual input receives)
+                train_bn = i in aux
                 nw = len(op.convs)
+                if train_bn:
+                    z, stats = aux.pop(i)
+                    bn_need = any(need[j] for j in op.pidx[nw + (nw if op.has_bias else 0):])
+                    dz, dg, db = ops.bn_train_backward(dz, z, stats, op.bn.weight.detach(), want_params=bn_need)
+                    del z
+                    scale, shift, invstd = None, None, None
+                else:
+                    scale, shift, invstd = self.fold(op)
                 w_need = [need[j] for j in op.pidx[:nw]]
                 rest = op.pidx[nw:]
                 b_idx = rest[:nw] if op.has_bias else []
                 bn_idx = rest[len(b_idx):]
-                want_bn = op.bn is not None and any(need[j] for j in bn_idx)
+                want_bn = (not train_bn) and op.bn is not None and any(need[j] for j in bn_idx)
                 want_bias = any(need[j] for j in b_idx)
+                if train_bn and bn_need:
+                    grads[bn_idx[0]], grads[bn_idx[1]] = dg, db
                 sums, dot = None, None
                 if any(w_need) or want_bn:
                     if want_bn:
@@ -299,7 +320,10 @@ class Engine:
                             grads[j] = dw
                 elif want_bias:
                     sums = ops.channel_sums(dz)
-                if op.bn is not None:
+                if train_bn:
+                    if want_bias:
+                        grads[b_idx[0]] = sums
+                elif op.bn is not None:
                     cb = op.convs[0].bias.detach() if op.has_bias else None
                     dg, db, dcb = ops.bn_param_grads(dot, sums, op.bn.running_mean, invstd, scale, cb,
                                                      want_gamma=want_bn, want_beta=want_bn, want_bias=want_bias) \
@@ -321,7 +345,7 @@ class Engine:
                                                table=self.table(op, OH, OW, True, dz.device),
                                                packed=self.packed(op, True, scale))
                 if op.res is not None:
-                    join_identity(op.res, dz)
+                    join_identity(op.res, dy_out)
             elif op.kind == "pool":
                 assert self.consumers[op.src] == 1
                 pending[op.src] -= 1

@@ -450,3 +450,73 @@ class EmaPlan:
                                      float(momentum), int(bool(update)), self.sq.data_ptr(), out.data_ptr(), L.stream_ptr()),
                 "dasac_ema_update")
         return out
+
+
+# ----------------------------------------------------------------------------------------------
+# train-mode BatchNorm (batch statistics; SyncBN when a process group with >1 ranks exists)
+# ----------------------------------------------------------------------------------------------
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _allreduce_sums(sums, count):
+    """SyncBN: one all-reduce of the raw sums (+ element count) over RCCL; identity on one rank."""
+    if _world() == 1:
+        return sums, float(count)
+    import torch.distributed as dist
+    packed = torch.cat([sums, torch.tensor([float(count)], dtype=torch.float64, device=sums.device)])
+    dist.all_reduce(packed)
+    return packed[:-1].contiguous(), float(packed[-1])
+
+
+def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
+    """y = relu?(BN_batch(z) (+res)); returns (y, (mean, invstd, count)).  Updates bn.running_* like ATen."""
+    lib = L.load()
+    L.require_gpu(z, res)
+    N, Cn = z.shape[0], z.shape[1]
+    HW = z[0, 0].numel()
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
+    L.check(lib.dasac_bn_stats(z.data_ptr(), N, Cn, HW, sums.data_ptr(), L.stream_ptr()), "dasac_bn_stats")
+    sums, count = _allreduce_sums(sums, N * HW)
+    scale, shift, mean, invstd = (_f32((Cn,), z) for _ in range(4))
+    mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+    upd = update_running and bn.track_running_stats
+    L.check(lib.dasac_bn_train_finalize(sums.data_ptr(), count, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                        bn.running_mean.data_ptr() if upd else None, bn.running_var.data_ptr() if upd else None,
+                                        float(mom), float(bn.eps), Cn, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                        invstd.data_ptr(), L.stream_ptr()), "dasac_bn_train_finalize")
+    if upd:
+        bn.num_batches_tracked += 1
+    y = torch.empty_like(z)
+    L.check(lib.dasac_bn_apply(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), int(relu), N, Cn, HW, y.data_ptr(),
+                               L.stream_ptr()), "dasac_bn_apply")
+    return y, (mean, invstd, count)
+
+
+def bn_train_backward(dy, z, stats, gamma, want_params=True):
+    """dy: gradient w.r.t. the BN output (ReLU mask already applied).  Returns (dz, dgamma, dbeta)."""
+    lib = L.load()
+    L.require_gpu(dy, z)
+    mean, invstd, count = stats
+    N, Cn = z.shape[0], z.shape[1]
+    HW = z[0, 0].numel()
+    dy = _c(dy)
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
+    L.check(lib.dasac_bn_bwd_reduce(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), N, Cn, HW, sums.data_ptr(),
+                                    L.stream_ptr()), "dasac_bn_bwd_reduce")
+    local = sums
+    if _world() > 1:
+        import torch.distributed as dist
+        sums = sums.clone()
+        dist.all_reduce(sums)
+    dz = torch.empty_like(z)
+    dg = _f32((Cn,), z) if want_params else None
+    db = _f32((Cn,), z) if want_params else None
+    L.check(lib.dasac_bn_bwd_apply(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                   sums.data_ptr(), float(count), N, Cn, HW, dz.data_ptr(), None, None, L.stream_ptr()),
+            "dasac_bn_bwd_apply")
+    if want_params:     # parameter gradients are LOCAL sums (DDP averages them across ranks afterwards)
+        dg.copy_(local[Cn:].to(torch.float32))
+        db.copy_(local[:Cn].to(torch.float32))
+    return dz, dg, db

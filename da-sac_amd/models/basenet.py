@@ -108,9 +108,6 @@ class BaseNet(nn.Module):
     def _logits(self, im):
         if self._engine is None:
             self._engine = E.Engine(self._plan())
-        if not self._bn_frozen():
-            raise NotImplementedError("train-mode (batch-statistics) BatchNorm is not available in the HIP engine yet; "
-                                      "use MODEL.BASELINE=False / freeze_bn=True or call .eval()")
         return E.run_plan(self._engine, im)
 
     def _segment(self, im, y, with_logits=True):

@@ -179,6 +179,29 @@ int dasac_add(const float* a, const float* b, float* out, int64_t n, dasac_strea
 /* out = y > 0 ? dy : 0  (ReLU backward, F.relu / nn.ReLU(inplace) of deeplabv2.py:84,88,97) */
 int dasac_relu_mask(const float* dy, const float* y, float* out, int64_t n, dasac_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm (baseline / AdaBN mode, models/__init__.py:29; nn.SyncBatchNorm of
+ * deeplabv2.py:15, fcn.py:8; running-stat re-estimation of train.py:281-289).
+ * forward:  dasac_bn_stats (sums[0:C] = sum z, sums[C:2C] = sum z^2, doubles) -> [caller all-reduces
+ *           `sums` and the element count across ranks = SyncBN] -> dasac_bn_train_finalize (batch
+ *           mean / biased var -> scale, shift, mean, invstd; running stats updated with momentum and
+ *           the unbiased var; running_* may be NULL) -> dasac_bn_apply (y = relu?(z*scale+shift(+res))).
+ * backward: dasac_bn_bwd_reduce (sums = sum dy, sum dy*xhat) -> [all-reduce] -> dasac_bn_bwd_apply
+ *           (dz = gamma*invstd*(dy - sum_dy/n - xhat*sum_dy_xhat/n); dgamma, dbeta optional).
+ */
+int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, dasac_stream_t stream);
+int dasac_bn_train_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int C,
+                            float* scale, float* shift, float* mean, float* invstd,
+                            dasac_stream_t stream);
+int dasac_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu,
+                   int N, int C, int64_t HW, float* y, dasac_stream_t stream);
+int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd,
+                        int N, int C, int64_t HW, double* sums, dasac_stream_t stream);
+int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const float* invstd,
+                       const float* gamma, const double* sums, double count, int N, int C, int64_t HW,
+                       float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
