@@ -866,3 +866,155 @@ extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, in
   DASAC_CHECK_LAUNCH("wgrad_reduce");
   return DASAC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// "Tap-expanded" evaluation of few-output-channel, many-tap convolutions (the ASPP classifiers:
+// 4 x (3x3, dilation 6..24), 2048|1024 -> 19, deeplabv2.py:101-116).  A 19-row GEMM wastes 40 % of a
+// 32-row MFMA tile and re-reads the activations once per tap; instead
+//    forward :  Y[(tap,co)][p] = sum_ci W[co,ci,tap] x[ci][p]      -- ONE dense 1x1 GEMM, M = taps*Cp
+//               out[co][p]     = bias[co] + sum_tap Y[(tap,co)][p + shift(tap)]            (tap_gather)
+//    backward:  D[(tap,co)][p'] = dout[co][p' - shift(tap)]                                 (tap_scatter)
+//               dW = 1x1 wgrad(D, x),  dx = 1x1 dgrad(D)  -- again dense GEMMs over taps*Cp channels.
+// Cp >= Cout pads the channel count so that taps*Cp is a multiple of 16 (FAST path of conv_gemm).
+// ------------------------------------------------------------------------------------------------
+namespace dasac {
+
+struct TapShifts {
+  int n;
+  short dh[64], dw[64];
+};
+
+// transposed = 0: k = ci, m = (tap0+tap)*Cp + co ;  transposed = 1: k = (tap0+tap)*Cp + co, m = ci
+__global__ void pack_expanded(const float* __restrict__ Wt, float* __restrict__ Wp, int Cout, int Cin, int taps, int tap0,
+                              int Cp, int Mpad, int transposed) {
+  const int64_t total = (int64_t)Cout * Cin * taps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const int64_t r = i / taps;
+    const int ci = (int)(r % Cin), co = (int)(r / Cin);
+    const int e = (tap0 + tap) * Cp + co;
+    const int64_t k = transposed ? e : ci;
+    const int m = transposed ? ci : e;
+    Wp[((k >> 2) * Mpad + m) * 4 + (k & 3)] = Wt[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void tap_gather(const float* __restrict__ Y, TapShifts ts, int Cp, int Cout,
+                                                  const float* __restrict__ bias, int H, int W, float* __restrict__ out,
+                                                  int64_t total) {
+  const int HW = H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const int64_t r = i / HW;
+    const int co = (int)(r % Cout);
+    const int64_t b = r / Cout;
+    const int oh = p / W, ow = p - oh * W;
+    const float* yb = Y + (size_t)b * ts.n * Cp * HW;
+    float acc = bias ? bias[co] : 0.f;
+    for (int t = 0; t < ts.n; ++t) {
+      const int ih = oh + ts.dh[t], iw = ow + ts.dw[t];
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) acc += yb[(size_t)(t * Cp + co) * HW + ih * W + iw];
+    }
+    out[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void tap_scatter(const float* __restrict__ dout, TapShifts ts, int Cp, int Cout, int H,
+                                                   int W, float* __restrict__ D, int64_t total) {
+  const int HW = H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const int64_t r = i / HW;
+    const int e = (int)(r % (ts.n * Cp));
+    const int64_t b = r / (ts.n * Cp);
+    const int t = e / Cp, co = e - t * Cp;
+    const int ih = p / W - ts.dh[t], iw = p % W - ts.dw[t];
+    float v = 0.f;
+    if (co < Cout && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+      v = dout[((size_t)b * Cout + co) * HW + ih * W + iw];
+    D[i] = v;
+  }
+}
+
+// dW[co][ci][tap] = sum_s P[s][(tap0+tap)*Cp + co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_expanded(const float* __restrict__ P, int splits, int Mpad, int Kpad,
+                                                             float* __restrict__ dW, int Cout, int Cin, int taps, int tap0,
+                                                             int Cp) {
+  const int64_t total = (int64_t)Cout * taps * Cin;
+  const size_t slab = (size_t)Mpad * Kpad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(i % Cin);                       // slab reads coalesce along ci
+    const int64_t r = i / Cin;
+    const int tap = (int)(r % taps), co = (int)(r / taps);
+    const size_t idx = (size_t)((tap0 + tap) * Cp + co) * Kpad + ci;
+    float g = 0.f;
+    for (int s = 0; s < splits; ++s) g += P[s * slab + idx];
+    dW[((size_t)co * Cin + ci) * taps + tap] = g;
+  }
+}
+
+static int fill_shifts(TapShifts& ts, const int32_t* kh, const int32_t* kw, const int32_t* dil, const int32_t* pad, int nb) {
+  ts.n = 0;
+  for (int b = 0; b < nb; ++b)
+    for (int a = 0; a < kh[b]; ++a)
+      for (int c = 0; c < kw[b]; ++c) {
+        if (ts.n >= 64) return fail(DASAC_EINVAL, "tap-expanded conv: more than 64 taps");
+        ts.dh[ts.n] = (short)(a * dil[b] - pad[b]);
+        ts.dw[ts.n] = (short)(c * dil[b] - pad[b]);
+        ++ts.n;
+      }
+  return DASAC_OK;
+}
+
+}  // namespace dasac
+
+extern "C" int dasac_conv_pack_expanded(const float* w, int Cout, int Cin, int taps, int tap0, int total_taps, int Cp,
+                                        int transposed, float* packed, dasac_stream_t stream) {
+  DASAC_REQUIRE(w && packed && Cp >= Cout, "conv_pack_expanded: bad arguments");
+  const int E = total_taps * Cp;
+  const int M = transposed ? Cin : E, K = transposed ? E : Cin;
+  const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
+  hipStream_t s = as_stream(stream);
+  if (tap0 == 0) DASAC_HIP(hipMemsetAsync(packed, 0, (size_t)Kpad * Mpad * sizeof(float), s));
+  hipLaunchKernelGGL(pack_expanded, dim3(stream_grid((int64_t)Cout * Cin * taps, 256)), dim3(256), 0, s, w, packed, Cout, Cin, taps,
+                     tap0, Cp, Mpad, transposed);
+  DASAC_CHECK_LAUNCH("pack_expanded");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_tap_gather(const float* y, const int32_t* kh, const int32_t* kw, const int32_t* dil, const int32_t* pad,
+                                int n_branches, int Cp, int Cout, const float* bias, int B, int H, int W, float* out,
+                                dasac_stream_t stream) {
+  DASAC_REQUIRE(y && out && kh && kw && dil && pad, "tap_gather: null pointer");
+  TapShifts ts;
+  int rc = fill_shifts(ts, kh, kw, dil, pad, n_branches);
+  if (rc) return rc;
+  const int64_t total = (int64_t)B * Cout * H * W;
+  hipLaunchKernelGGL(tap_gather, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), y, ts, Cp, Cout, bias, H, W, out, total);
+  DASAC_CHECK_LAUNCH("tap_gather");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_tap_scatter(const float* dout, const int32_t* kh, const int32_t* kw, const int32_t* dil,
+                                 const int32_t* pad, int n_branches, int Cp, int Cout, int B, int H, int W, float* d,
+                                 dasac_stream_t stream) {
+  DASAC_REQUIRE(dout && d && kh && kw && dil && pad, "tap_scatter: null pointer");
+  TapShifts ts;
+  int rc = fill_shifts(ts, kh, kw, dil, pad, n_branches);
+  if (rc) return rc;
+  const int64_t total = (int64_t)B * ts.n * Cp * H * W;
+  hipLaunchKernelGGL(tap_scatter, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), dout, ts, Cp, Cout, H, W, d, total);
+  DASAC_CHECK_LAUNCH("tap_scatter");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, int OH, int OW, int E, int Cin, float* dw,
+                                                int Cout, int taps, int tap0, int Cp, dasac_stream_t stream) {
+  DASAC_REQUIRE(workspace && dw, "conv_wgrad_finish_expanded: null pointer");
+  const int Mpad = dasac_conv_mpad(E), Kpad = dasac_conv_kpad(Cin);
+  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
+  hipLaunchKernelGGL(wgrad_reduce_expanded, dim3(stream_grid((int64_t)Cout * taps * Cin, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float*>(workspace), splits, Mpad, Kpad, dw, Cout, Cin, taps, tap0, Cp);
+  DASAC_CHECK_LAUNCH("wgrad_reduce_expanded");
+  return DASAC_OK;
+}

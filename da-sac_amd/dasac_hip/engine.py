@@ -38,6 +38,8 @@ class ConvOp:
         self.spec = ops.ConvSpec(c0.in_channels, c0.out_channels, branches, c0.stride[0])
         self.has_bias = c0.bias is not None
         assert bn is None or len(convs) == 1
+        # few output channels x many taps (ASPP): evaluate as dense 1x1 GEMMs over taps*Cp channels
+        self.expanded = ops.ExpandedConv(self.spec) if (len(convs) > 1 and c0.out_channels <= 32 and c0.stride[0] == 1) else None
 
     def params(self):
         out = [c.weight for c in self.convs]
@@ -190,6 +192,24 @@ class Engine:
             self._folds[id(op)] = ent
         return ent[1]
 
+    def table_e(self, op, h, w, transposed, device):
+        key = (id(op), "e", h, w, transposed, device.index)
+        t = self._tables.get(key)
+        if t is None:
+            t = ops.conv_table(op.expanded.spec1, h, w, transposed, device)
+            self._tables[key] = t
+        return t
+
+    def packed_e(self, op, transposed):
+        key = tuple(_ver(c.weight) for c in op.convs)
+        slot = (id(op), "e", transposed)
+        ent = self._packs.get(slot)
+        if ent is None or ent[0] != key:
+            buf = op.expanded.pack([c.weight.detach() for c in op.convs], transposed, out=None if ent is None else ent[1])
+            ent = (key, buf)
+            self._packs[slot] = ent
+        return ent[1]
+
     def packed(self, op, transposed, scale=None):
         key = tuple(_ver(c.weight) for c in op.convs) + ((_ver(scale),) if scale is not None else ())
         slot = (id(op), transposed)
@@ -212,6 +232,14 @@ class Engine:
             if op.kind == "conv":
                 Nb, _, H, W = xin.shape
                 OH, OW = op.spec.out_hw(H, W)
+                if op.expanded is not None:
+                    _, bias_sum, _ = self.fold(op)
+                    acts[op.dst] = op.expanded.forward(xin, self.packed_e(op, False), self.table_e(op, H, W, False, xin.device), bias_sum)
+                    if not keep:
+                        for s_ in self._inputs(op):
+                            if self.last_use[s_] == i and s_ != 0:
+                                del acts[s_]
+                    continue
                 out = torch.empty((Nb, op.spec.cout, OH, OW), dtype=torch.float32, device=xin.device)
                 if op.bn is not None and op.bn.training:
                     # batch-statistics BN (baseline / AdaBN mode): raw conv, then stats -> normalise(+res)(+ReLU)
@@ -288,6 +316,27 @@ class Engine:
             if op.kind == "conv":
                 spec = op.spec
                 Nb, _, H, W = xin.shape
+                if op.expanded is not None:
+                    ex, nw_ = op.expanded, len(op.convs)
+                    d = ex.scatter(dz)
+                    if any(need[j] for j in op.pidx[:nw_]):
+                        dws = ex.wgrad(d, xin, [c.weight.detach() for c in op.convs], self.table_e(op, H, W, False, xin.device))
+                        for j, dw in zip(op.pidx[:nw_], dws):
+                            if need[j]:
+                                grads[j] = dw
+                    if op.has_bias and any(need[j] for j in op.pidx[nw_:]):
+                        sums = ops.channel_sums(dz)
+                        for n_, j in enumerate(op.pidx[nw_:]):
+                            if need[j]:
+                                grads[j] = sums if n_ == 0 else sums.clone()
+                    if op.src != 0:
+                        pending[op.src] -= 1
+                        last = pending[op.src] == 0
+                        mask = acts[op.src] if (last and relu_producer(op.src)) else None
+                        g[op.src] = ex.dgrad(d, self.packed_e(op, True), self.table_e(op, H, W, True, dz.device), (H, W),
+                                             res=g.get(op.src), mask=mask)
+                    acts.pop(op.dst, None)
+                    continue
                 dy_out = dz                       # gradient w.r.t. the op output (what a residual input receives)
                 train_bn = i in aux
                 nw = len(op.convs)

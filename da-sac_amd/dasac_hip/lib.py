@@ -49,6 +49,10 @@ PROTOTYPES = {
     "dasac_bn_apply": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p, _p]),
     "dasac_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p]),
     "dasac_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, C.c_double, _i, _i, _l, _p, _p, _p, _p]),
+    "dasac_conv_pack_expanded": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_tap_gather": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "dasac_tap_scatter": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_conv_wgrad_finish_expanded": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

@@ -520,3 +520,81 @@ def bn_train_backward(dy, z, stats, gamma, want_params=True):
         dg.copy_(local[Cn:].to(torch.float32))
         db.copy_(local[:Cn].to(torch.float32))
     return dz, dg, db
+
+
+# ----------------------------------------------------------------------------------------------
+# tap-expanded convolution (ASPP classifiers): dense 1x1 GEMMs over taps*Cp channels + shift kernels
+# ----------------------------------------------------------------------------------------------
+class ExpandedConv:
+    """Static description: `spec` (multi-branch, stride 1) -> 1x1 spec over E = taps*Cp expanded channels."""
+
+    def __init__(self, spec):
+        assert spec.stride == 1 and spec.taps <= 64
+        self.spec = spec
+        cp = spec.cout
+        while (spec.taps * cp) % 16:
+            cp += 1
+        self.cp, self.E = cp, spec.taps * cp
+        self.spec1 = ConvSpec(spec.cin, self.E, [(1, 1, 1, 0)], 1)
+        self._cols = [torch.tensor(c, dtype=_i32) for c in zip(*spec.branches)]      # host arrays kh, kw, dil, pad
+
+    def _branch_args(self):
+        c = self._cols
+        return c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), len(self.spec.branches)
+
+    def pack(self, weights, transposed, out=None):
+        lib = L.load()
+        M = self.spec.cin if transposed else self.E
+        K = self.E if transposed else self.spec.cin
+        if out is None:
+            out = torch.empty((lib.dasac_conv_kpad(K), lib.dasac_conv_mpad(M)), dtype=torch.float32, device=weights[0].device)
+        tap0 = 0
+        for w, (kh, kw, _, _) in zip(weights, self.spec.branches):
+            L.check(lib.dasac_conv_pack_expanded(_c(w).data_ptr(), self.spec.cout, self.spec.cin, kh * kw, tap0, self.spec.taps,
+                                                 self.cp, int(transposed), out.data_ptr(), L.stream_ptr()), "dasac_conv_pack_expanded")
+            tap0 += kh * kw
+        return out
+
+    def forward(self, x, packed, table, bias):
+        """x [B,Cin,H,W] -> out [B,Cout,H,W]."""
+        lib = L.load()
+        B, _, H, W = x.shape
+        y = torch.empty((B, self.E, H, W), dtype=torch.float32, device=x.device)
+        conv_gemm(x, packed, table, y, (H, W), 1, self.E, self.spec.cin)
+        out = torch.empty((B, self.spec.cout, H, W), dtype=torch.float32, device=x.device)
+        L.check(lib.dasac_tap_gather(y.data_ptr(), *self._branch_args(), self.cp, self.spec.cout, L.ptr(bias), B, H, W,
+                                     out.data_ptr(), L.stream_ptr()), "dasac_tap_gather")
+        return out
+
+    def scatter(self, dout):
+        lib = L.load()
+        B, _, H, W = dout.shape
+        d = torch.empty((B, self.E, H, W), dtype=torch.float32, device=dout.device)
+        L.check(lib.dasac_tap_scatter(_c(dout).data_ptr(), *self._branch_args(), self.cp, self.spec.cout, B, H, W, d.data_ptr(),
+                                      L.stream_ptr()), "dasac_tap_scatter")
+        return d
+
+    def wgrad(self, d, x, weights, table):
+        """Weight gradients of every branch from the expanded gradient d [B,E,H,W]."""
+        lib = L.load()
+        B, Cx, H, W = x.shape
+        nbytes = lib.dasac_conv_wgrad_workspace(B, H, W, self.E, self.spec.cin)
+        ws = L.workspace(nbytes, x.device)
+        with PROFILE.span("conv_wgrad", 2.0 * B * H * W * self.E * self.spec.cin):
+            L.check(lib.dasac_conv_wgrad(d.data_ptr(), x.data_ptr(), table.data_ptr(), B, Cx, H, W, H, W, 1, self.E, self.spec.cin,
+                                         ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
+        grads, tap0 = [], 0
+        for w, (kh, kw, _, _) in zip(weights, self.spec.branches):
+            dw = torch.empty_like(w)
+            L.check(lib.dasac_conv_wgrad_finish_expanded(ws.data_ptr(), B, H, W, self.E, self.spec.cin, dw.data_ptr(),
+                                                         self.spec.cout, kh * kw, tap0, self.cp, L.stream_ptr()),
+                    "dasac_conv_wgrad_finish_expanded")
+            grads.append(dw)
+            tap0 += kh * kw
+        return grads
+
+    def dgrad(self, d, packed_t, table_t, in_hw, res=None, mask=None):
+        B = d.shape[0]
+        H, W = in_hw
+        dx = torch.empty((B, self.spec.cin, H, W), dtype=torch.float32, device=d.device)
+        return conv_gemm(d, packed_t, table_t, dx, (H, W), 1, self.spec.cin, self.E, 1, None, res, mask, False)

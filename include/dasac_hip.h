@@ -100,6 +100,23 @@ int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M
                             const float* w, const float* scale, float* dw, float* dot,
                             float* sum_dz, int Cin, int taps, int tap0, dasac_stream_t stream);
 
+/* Tap-expanded evaluation of few-output-channel, many-tap convolutions -- the ASPP classifiers
+ * (deeplabv2.py:101-116): Y[(tap,co)] = 1x1 GEMM over taps*Cp channels (dasac_conv_gemm with weights
+ * from dasac_conv_pack_expanded), out = bias + sum_tap shift(Y) (dasac_tap_gather); backward:
+ * D = dasac_tap_scatter(dout), then plain 1x1 wgrad / dgrad on D.  Cp >= Cout pads the channels so
+ * that taps*Cp % 16 == 0.  Branches are (kh,kw,dilation,padding) as for dasac_conv_table. */
+int dasac_conv_pack_expanded(const float* w, int Cout, int Cin, int taps, int tap0, int total_taps,
+                             int Cp, int transposed, float* packed, dasac_stream_t stream);
+int dasac_tap_gather(const float* y, const int32_t* kh, const int32_t* kw, const int32_t* dil,
+                     const int32_t* pad, int n_branches, int Cp, int Cout, const float* bias, int B,
+                     int H, int W, float* out, dasac_stream_t stream);
+int dasac_tap_scatter(const float* dout, const int32_t* kh, const int32_t* kw, const int32_t* dil,
+                      const int32_t* pad, int n_branches, int Cp, int Cout, int B, int H, int W,
+                      float* d, dasac_stream_t stream);
+int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, int OH, int OW, int E, int Cin,
+                                     float* dw, int Cout, int taps, int tap0, int Cp,
+                                     dasac_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * SAC head (models/sac.py) -- HBM-bound streaming kernels over [B,C,H,W] fp32, C <= 32.
  *
