@@ -451,9 +451,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
     const int xbase = pn * g.CxHW + ih0 * g.W + iw0;                                                 \
     if (FAST) {                                                                                      \
       const unsigned vz = pv ? (unsigned)(zbase + prow * OHW) * 4u : kPoison;                        \
-      _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                          \
-        ra[i] = (m0 + i * 8 < g.M) ? buf_f32(rz, vz, (m0 + i * 8) * OHW * 4) : 0.f;                  \
-        if (do_sums) rsum[i] += ra[i];                                                               \
+      /* rows past M (last, partial M tile) re-read the last valid 8-row group: their products land */ \
+      /* in slab rows >= M that nobody reads -- no per-row branch or select in the loop            */ \
+      _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                            \
+        ra[i] = buf_f32(rz, vz, min(m0 + i * 8, g.M - 8) * OHW * 4);                                 \
+      if (do_sums) {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) rsum[i] += ra[i];                        \
       }                                                                                              \
       const int ih = ih0 + e0.y, iw = iw0 + e0.z;                                                    \
       const bool ok = pv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);          \
