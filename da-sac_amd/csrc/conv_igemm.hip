@@ -798,8 +798,10 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
 
 // Number of pixel splits: every block of a wgrad launch runs for the same time, so pick the split count
 // whose block total fills whole rounds of resident blocks (2 per CU for the 128-row tile, 3 otherwise).
-static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM) {
-  const int tiles = (Mpad / BM) * (Kpad / 128);
+static int wgrad_bn(int Cx) { return (Cx % 128 != 0 && Cx % 64 == 0) ? 64 : 128; }   // k-tile rows: one tap per tile when possible
+
+static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM, int BNk = 128) {
+  const int tiles = (Mpad / BM) * (Kpad / BNk);
   const int slots = kNumCu * (BM == 128 ? 2 : 3);
   int max_splits = (Npix + 1023) / 1024;                    // at least 1024 pixels per split
   if (max_splits > 64) max_splits = 64;
@@ -820,7 +822,9 @@ static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM) {
 
 extern "C" size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K) {
   const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
-  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
+  // upper bound over both k-tile widths (the width depends on Cx, unknown here)
+  const int s128 = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad), 128), s64 = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad), 64);
+  const int splits = s128 > s64 ? s128 : s64;
   return (size_t)splits * Mpad * (Kpad + 1) * sizeof(float);     // slabs + per-split channel sums
 }
 
@@ -833,7 +837,8 @@ extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* 
   int rc = fill_geom(g, Nb, Cx, H, W, OH, OW, stride, M, Mpad, Kpad, OH, OW, 1);
   if (rc) return rc;
   const int bm = pick_bm(Mpad);
-  const int splits = wgrad_splits(Mpad, Kpad, g.Npix, bm);
+  const int bnk = (M % 8 == 0 && bm != 32) ? wgrad_bn(Cx) : 128;
+  const int splits = wgrad_splits(Mpad, Kpad, g.Npix, bm, bnk);
   if (ws_bytes < (size_t)splits * Mpad * (Kpad + 1) * sizeof(float)) return fail(DASAC_EWORKSPACE, "conv_wgrad: workspace too small");
   int per = (g.Npix + splits - 1) / splits;
   per = (per + kWgPix - 1) / kWgPix * kWgPix;
@@ -842,6 +847,12 @@ extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* 
   float* Psum = P + (size_t)splits * Mpad * Kpad;
   hipStream_t s = as_stream(stream);
   const bool fast = (Cx % 128 == 0) && (M % 8 == 0);   // a 128-row k tile sits inside one tap
+  if (bnk == 64) {                                     // Cx = 64, 192, ...: 64-row k tiles, still one tap each
+    if (bm == 128) launch_wgrad<128, 64, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
+    else launch_wgrad<64, 64, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
+    DASAC_CHECK_LAUNCH("conv_wgrad");
+    return DASAC_OK;
+  }
   switch (bm) {
     case 128:
       if (fast) launch_wgrad<128, 128, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
@@ -862,7 +873,8 @@ extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, in
                                        int tap0, dasac_stream_t stream) {
   DASAC_REQUIRE(workspace && w && dw, "conv_wgrad_finish: null pointer");
   const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
-  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
+  const int bm = pick_bm(Mpad);
+  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, bm, (M % 8 == 0 && bm != 32) ? wgrad_bn(Cin) : 128);
   const float* P = reinterpret_cast<const float*>(workspace);
   hipLaunchKernelGGL(wgrad_reduce, dim3((Cin * taps + 1023) / 1024, M), dim3(256), 0, as_stream(stream), P,
                      P + (size_t)splits * Mpad * Kpad, splits, Mpad, Kpad, w, scale, dw, dot, sum_dz, Cin, taps, tap0);
@@ -1015,7 +1027,8 @@ extern "C" int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, i
                                                 int Cout, int taps, int tap0, int Cp, dasac_stream_t stream) {
   DASAC_REQUIRE(workspace && dw, "conv_wgrad_finish_expanded: null pointer");
   const int Mpad = dasac_conv_mpad(E), Kpad = dasac_conv_kpad(Cin);
-  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, pick_bm(Mpad));
+  const int bm = pick_bm(Mpad);
+  const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, bm, (E % 8 == 0 && bm != 32) ? wgrad_bn(Cin) : 128);
   hipLaunchKernelGGL(wgrad_reduce_expanded, dim3(stream_grid((int64_t)Cout * taps * Cin, 256)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float*>(workspace), splits, Mpad, Kpad, dw, Cout, Cin, taps, tap0, Cp);
   DASAC_CHECK_LAUNCH("wgrad_reduce_expanded");
