@@ -555,14 +555,33 @@ struct TapGroups {
   int kh[4], kw[4], dil[4], pad[4];
 };
 
-// table row k = tap*C + c  (tap-major), tap enumerates (branch, kh, kw)
-__global__ void build_table(int4* tab, TapGroups tg, int C, int K, int Kpad, int planeHW, int W, int sign) {
+// table row k -> (tap, c); tap enumerates (branch, kh, kw).
+//   order 0 (tap-major):    k = tap*C + c                         -- weight-gradient tiles want one tap per 128 rows
+//   order 1 (chunk-major):  k = ((c/16)*taps + tap)*16 + c%16     -- forward / data gradient: consecutive K-steps
+//       walk the taps of the SAME 16 channel planes, so the shifted re-reads of a dilated 3x3 hit L2
+//       instead of streaming the whole channel range between two taps (needs C % 16 == 0)
+__device__ __forceinline__ void decode_k(int k, int C, int taps, int order, int& tap, int& c) {
+  if (order == 0) {
+    tap = k / C;
+    c = k - tap * C;
+  } else {
+    const int blk = k >> 4, chunk = blk / taps;
+    tap = blk - chunk * taps;
+    c = chunk * 16 + (k & 15);
+  }
+}
+__device__ __forceinline__ int encode_k(int tap, int c, int C, int taps, int order) {
+  return order == 0 ? tap * C + c : (((c >> 4) * taps + tap) << 4) + (c & 15);
+}
+
+__global__ void build_table(int4* tab, TapGroups tg, int C, int K, int Kpad, int planeHW, int W, int sign, int taps,
+                            int order) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Kpad) return;
   int4 e = make_int4(0, kInvalid, kInvalid, 0);
   if (k < K) {
-    int tap = k / C;
-    const int c = k - tap * C;
+    int tap, c;
+    decode_k(k, C, taps, order, tap, c);
     int b = 0;
     while (b < tg.n - 1 && tap >= tg.kh[b] * tg.kw[b]) {
       tap -= tg.kh[b] * tg.kw[b];
@@ -578,12 +597,12 @@ __global__ void build_table(int4* tab, TapGroups tg, int C, int K, int Kpad, int
 // mode 0 (forward):  Wp[(tap0+tap)*Cin + ci][co] = W[co][ci][tap] * (scale ? scale[co] : 1)
 // mode 1 (dgrad):    Wp[(tap0+tap)*Cout + co][ci] = W[co][ci][tap] * (scale ? scale[co] : 1)
 __global__ void pack_weights(const float* __restrict__ Wt, const float* __restrict__ scale, float* __restrict__ Wp,
-                             int Cout, int Cin, int taps, int tap0, int Mpad, int mode) {
-  const int rows = taps * (mode == 0 ? Cin : Cout);
+                             int Cout, int Cin, int taps, int tap0, int total_taps, int Mpad, int mode, int order) {
+  const int C = mode == 0 ? Cin : Cout;
+  const int rows = taps * C;
   const int64_t total = (int64_t)rows * Mpad;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / Mpad), m = (int)(i - (int64_t)row * Mpad);
-    const int C = mode == 0 ? Cin : Cout;
     const int tap = row / C, c = row - tap * C;
     float v = 0.f;
     if (mode == 0) {
@@ -597,7 +616,7 @@ __global__ void pack_weights(const float* __restrict__ Wt, const float* __restri
         if (scale) v = v * scale[c];
       }
     }
-    const int64_t k = (int64_t)tap0 * C + row;
+    const int64_t k = encode_k(tap0 + tap, c, C, total_taps, order);
     Wp[((k >> 2) * Mpad + m) * 4 + (k & 3)] = v;   // k-interleaved: [(k/4)][m][k%4]
   }
 }
@@ -717,7 +736,7 @@ extern "C" int dasac_conv_mpad(int M) { return M > 64 ? (M + 127) / 128 * 128 : 
 extern "C" int dasac_conv_kpad(int K) { return (K + 127) / 128 * 128; }
 
 extern "C" int dasac_conv_table(const int32_t* kh, const int32_t* kw, const int32_t* dil, const int32_t* pad,
-                                int n_branches, int C, int plane_h, int plane_w, int transposed, int32_t* table,
+                                int n_branches, int C, int plane_h, int plane_w, int transposed, int order, int32_t* table,
                                 dasac_stream_t stream) {
   DASAC_REQUIRE(kh && kw && dil && pad && table, "conv_table: null pointer");
   DASAC_REQUIRE(n_branches >= 1 && n_branches <= 4 && C > 0, "conv_table: bad branches/C");
@@ -730,22 +749,24 @@ extern "C" int dasac_conv_table(const int32_t* kh, const int32_t* kw, const int3
   }
   for (int b = n_branches; b < 4; ++b) tg.kh[b] = tg.kw[b] = tg.dil[b] = tg.pad[b] = 1;
   const int K = taps * C, Kpad = dasac_conv_kpad(K);
+  DASAC_REQUIRE(order == 0 || (order == 1 && C % 16 == 0), "conv_table: chunk-major order needs C %% 16 == 0");
   hipLaunchKernelGGL(build_table, dim3((Kpad + 255) / 256), dim3(256), 0, as_stream(stream), reinterpret_cast<int4*>(table),
-                     tg, C, K, Kpad, plane_h * plane_w, plane_w, transposed ? -1 : 1);
+                     tg, C, K, Kpad, plane_h * plane_w, plane_w, transposed ? -1 : 1, taps, order);
   DASAC_CHECK_LAUNCH("build_table");
   return DASAC_OK;
 }
 
 extern "C" int dasac_conv_pack(const float* w, const float* scale, int Cout, int Cin, int taps, int tap0, int total_taps,
-                               int transposed, float* packed, dasac_stream_t stream) {
+                               int transposed, int order, float* packed, dasac_stream_t stream) {
   DASAC_REQUIRE(w && packed, "conv_pack: null pointer");
   const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
   const int Mpad = dasac_conv_mpad(M), K = total_taps * C, Kpad = dasac_conv_kpad(K);
   hipStream_t s = as_stream(stream);
   if (tap0 == 0 && Kpad > K) DASAC_HIP(hipMemsetAsync(packed, 0, (size_t)Kpad * Mpad * sizeof(float), s));   // zero K padding
   const int64_t total = (int64_t)taps * C * Mpad;
+  DASAC_REQUIRE(order == 0 || (order == 1 && C % 16 == 0), "conv_pack: chunk-major order needs C %% 16 == 0");
   hipLaunchKernelGGL(pack_weights, dim3(stream_grid(total, 256)), dim3(256), 0, s, w, scale, packed, Cout, Cin, taps, tap0,
-                     Mpad, transposed ? 1 : 0);
+                     total_taps, Mpad, transposed ? 1 : 0, order);
   DASAC_CHECK_LAUNCH("pack_weights");
   return DASAC_OK;
 }

@@ -159,11 +159,14 @@ class Engine:
         return [op.src]
 
     # ---------------------------------------------------------------- caches
-    def table(self, op, h, w, transposed, device):
-        key = (id(op), h, w, transposed, device.index)
+    def table(self, op, h, w, transposed, device, wgrad=False):
+        """Gather table; the forward / data-gradient GEMMs may use the chunk-major K order, the weight
+        gradient always the tap-major one."""
+        order = 0 if wgrad else ops.gemm_order(op.spec, transposed)
+        key = (id(op), h, w, transposed, device.index, order)
         t = self._tables.get(key)
         if t is None:
-            t = ops.conv_table(op.spec, h, w, transposed, device)
+            t = ops.conv_table(op.spec, h, w, transposed, device, order)
             self._tables[key] = t
         return t
 
@@ -216,7 +219,8 @@ class Engine:
         ent = self._packs.get(slot)
         if ent is None or ent[0] != key:
             buf = None if ent is None else ent[1]
-            buf = ops.conv_pack(op.spec, [c.weight.detach() for c in op.convs], transposed, scale, out=buf)
+            buf = ops.conv_pack(op.spec, [c.weight.detach() for c in op.convs], transposed, scale, out=buf,
+                                order=ops.gemm_order(op.spec, transposed))
             ent = (key, buf, scale)      # keep `scale` alive: its data_ptr is part of the key
             self._packs[slot] = ent
         return ent[1]
@@ -363,7 +367,7 @@ class Engine:
                     if want_bn or want_bias:      # channel sums ride along with the wgrad kernel
                         sums = torch.empty(spec.cout, dtype=torch.float32, device=dz.device)
                     dws = ops.conv_wgrad(spec, dz, xin, [c.weight.detach() for c in op.convs], scale=scale, dot=dot,
-                                         table=self.table(op, H, W, False, xin.device), sum_dz=sums)
+                                         table=self.table(op, H, W, False, xin.device, wgrad=True), sum_dz=sums)
                     for j, dw in zip(op.pidx[:nw], dws):
                         if need[j]:
                             grads[j] = dw

@@ -18,8 +18,8 @@ PROTOTYPES = {
     "dasac_pseudo_labels": (_i, [_p, _p, _p, _f, _f, _i, _i, _l, _p, _p, _p, _p, _sz, _p]),
     "dasac_conv_mpad": (_i, [_i]),
     "dasac_conv_kpad": (_i, [_i]),
-    "dasac_conv_table": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
-    "dasac_conv_pack": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_conv_table": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dasac_conv_pack": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_conv_gemm": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _i, _p, _sz, _p]),
     "dasac_conv_gemm_workspace": (_sz, []),
     "dasac_conv_gemm_schedule": (_i, [_i, _i, _i, _i, _i]),

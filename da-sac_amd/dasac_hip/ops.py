@@ -106,7 +106,14 @@ class ConvSpec:
 _i32 = torch.int32
 
 
-def conv_table(spec, plane_h, plane_w, transposed, device):
+def gemm_order(spec, transposed):
+    """K order of the forward / data-gradient GEMM: chunk-major (1) for multi-tap convs whose gathered channel
+    count is a multiple of 16, tap-major (0) otherwise.  The weight gradient always uses tap-major tables."""
+    C = spec.cout if transposed else spec.cin
+    return 1 if (spec.taps > 1 and C % 16 == 0 and os.environ.get("DASAC_KORDER", "1") != "0") else 0
+
+
+def conv_table(spec, plane_h, plane_w, transposed, device, order=0):
     """Gather table for planes of plane_h x plane_w (forward: the input planes; transposed: dz planes)."""
     lib = L.load()
     C = spec.cout if transposed else spec.cin
@@ -114,12 +121,12 @@ def conv_table(spec, plane_h, plane_w, transposed, device):
     table = torch.empty((lib.dasac_conv_kpad(K), 4), dtype=_i32, device=device)
     cols = [torch.tensor(c, dtype=_i32) for c in zip(*spec.branches)]   # host arrays: kh, kw, dil, pad
     L.check(lib.dasac_conv_table(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), cols[3].data_ptr(),
-                                 len(spec.branches), C, plane_h, plane_w, int(transposed), table.data_ptr(),
+                                 len(spec.branches), C, plane_h, plane_w, int(transposed), int(order), table.data_ptr(),
                                  L.stream_ptr()), "dasac_conv_table")
     return table
 
 
-def conv_pack(spec, weights, transposed, scale=None, out=None):
+def conv_pack(spec, weights, transposed, scale=None, out=None, order=0):
     """Packs the branch weight tensors [Cout,Cin,kh,kw] into the [Kpad][Mpad] GEMM operand."""
     lib = L.load()
     L.require_gpu(*weights)
@@ -131,7 +138,7 @@ def conv_pack(spec, weights, transposed, scale=None, out=None):
     tap0 = 0
     for w, (kh, kw, _, _) in zip(weights, spec.branches):
         L.check(lib.dasac_conv_pack(_c(w).data_ptr(), L.ptr(scale), spec.cout, spec.cin, kh * kw, tap0, spec.taps,
-                                    int(transposed), out.data_ptr(), L.stream_ptr()), "dasac_conv_pack")
+                                    int(transposed), int(order), out.data_ptr(), L.stream_ptr()), "dasac_conv_pack")
         tap0 += kh * kw
     return out
 
@@ -161,8 +168,9 @@ def conv_forward(spec, x, weights, scale=None, shift=None, res=None, relu=False,
     """Convenience forward: y = relu?(scale*conv(x) + shift + res); `scale` is folded into the packed weights."""
     Nb, _, H, W = x.shape
     OH, OW = spec.out_hw(H, W)
-    table = conv_table(spec, H, W, False, x.device) if table is None else table
-    packed = conv_pack(spec, weights, False, scale) if packed is None else packed
+    order = gemm_order(spec, False)
+    table = conv_table(spec, H, W, False, x.device, order) if table is None else table
+    packed = conv_pack(spec, weights, False, scale, order=order) if packed is None else packed
     out = torch.empty((Nb, spec.cout, OH, OW), dtype=torch.float32, device=x.device)
     return conv_gemm(x, packed, table, out, (OH, OW), spec.stride, spec.cout, spec.K, 1, shift, res, None, relu)
 
@@ -171,8 +179,9 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
     """dx = conv^T(dz * scale[co]) (+res) (masked).  stride 1 for any kernel; stride>1 only for 1x1."""
     Nb, _, OH, OW = dz.shape
     H, W = in_hw
-    table = conv_table(spec, OH, OW, True, dz.device) if table is None else table
-    packed = conv_pack(spec, weights, True, scale) if packed is None else packed
+    order = gemm_order(spec, True)
+    table = conv_table(spec, OH, OW, True, dz.device, order) if table is None else table
+    packed = conv_pack(spec, weights, True, scale, order=order) if packed is None else packed
     if spec.stride == 1:
         dx = torch.empty((Nb, spec.cin, H, W), dtype=torch.float32, device=dz.device)
         return conv_gemm(dz, packed, table, dx, (H, W), 1, spec.cin, spec.Kt, 1, None, res, mask, False)

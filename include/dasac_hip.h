@@ -60,7 +60,10 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *
  * A convolution is described by "tap branches" (kh,kw,dilation,padding): one branch for a plain
  * conv, four for the ASPP sum of deeplabv2.py:112-116 evaluated as a single contraction.
- *   K = (sum of kh*kw) * C,  k = tap*C + c (tap-major).
+ *   K = (sum of kh*kw) * C;  `order` 0: k = tap*C + c (tap-major, required by the weight gradient);
+ *   `order` 1: k = ((c/16)*taps + tap)*16 + c%16 (chunk-major, C % 16 == 0: the taps of a 16-channel
+ *   chunk are contracted back to back so their shifted re-reads stay in L2) -- table and packed
+ *   weights of one GEMM must use the same order.
  * dasac_conv_table   builds the gather table [Kpad][4] int32 for planes of plane_h x plane_w;
  *                    transposed=1 gives the data-gradient geometry (C = Cout, dh = pad - kh*dil).
  * dasac_conv_pack    lays W [Cout,Cin,kh,kw] out as the k-interleaved [Kpad/4][Mpad][4] GEMM operand
@@ -81,10 +84,10 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
 int dasac_conv_mpad(int M);
 int dasac_conv_kpad(int K);
 int dasac_conv_table(const int32_t* kh, const int32_t* kw, const int32_t* dil, const int32_t* pad,
-                     int n_branches, int C, int plane_h, int plane_w, int transposed,
+                     int n_branches, int C, int plane_h, int plane_w, int transposed, int order,
                      int32_t* table, dasac_stream_t stream);
 int dasac_conv_pack(const float* w, const float* scale, int Cout, int Cin, int taps, int tap0,
-                    int total_taps, int transposed, float* packed, dasac_stream_t stream);
+                    int total_taps, int transposed, int order, float* packed, dasac_stream_t stream);
 int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out,
                     int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                     int OutH, int OutW, int ostride,

@@ -87,16 +87,33 @@ def batchnorm(sd, prefix, x, train, momentum=BN_MOMENTUM):
     return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], train, momentum, BN_EPS)
 
 
-def bottleneck(sd, p, x, stride, dilation, bn_train):
-    """deeplabv2.py:79-99: stride sits on the first 1x1 (:59)."""
+def bottleneck(sd, p, x, stride, dilation, bn_train, act=F.relu):
+    """deeplabv2.py:79-99: stride sits on the first 1x1 (:59).  `act` = the ReLU (tests may inject a
+    mask-driven one, see MaskedRelu)."""
     y = F.conv2d(x, sd[p + ".conv1.weight"], stride=stride)
-    y = F.relu(batchnorm(sd, p + ".bn1", y, bn_train))
+    y = act(batchnorm(sd, p + ".bn1", y, bn_train))
     y = F.conv2d(y, sd[p + ".conv2.weight"], padding=dilation, dilation=dilation)
-    y = F.relu(batchnorm(sd, p + ".bn2", y, bn_train))
+    y = act(batchnorm(sd, p + ".bn2", y, bn_train))
     y = batchnorm(sd, p + ".bn3", F.conv2d(y, sd[p + ".conv3.weight"]), bn_train)
     if (p + ".downsample.0.weight") in sd:
         x = batchnorm(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), bn_train)
-    return F.relu(y + x)
+    return act(y + x)
+
+
+class MaskedRelu:
+    """ReLU whose on/off pattern is dictated from outside (one mask per call, in call order): y = z*mask.
+    Lets a test compare gradients of two fp32 implementations without the handful of units whose
+    pre-activation sits within round-off of zero deciding the outcome."""
+
+    def __init__(self, masks):
+        self.masks, self.i, self.disagree, self.total = list(masks), 0, 0, 0
+
+    def __call__(self, z):
+        m = self.masks[self.i].to(z.dtype)
+        self.i += 1
+        self.disagree += int(((z.detach() > 0) != (m > 0)).sum())
+        self.total += m.numel()
+        return z * m
 
 
 def aspp_sum(sd, p, x):
@@ -108,14 +125,14 @@ def aspp_sum(sd, p, x):
     return out
 
 
-def resnet101_logits(sd, x, bn_train=False, stages=RESNET101_STAGES):
+def resnet101_logits(sd, x, bn_train=False, stages=RESNET101_STAGES, act=F.relu):
     """deeplabv2.py:160-171."""
     y = F.conv2d(x, sd["model.conv1.weight"], stride=2, padding=3)
-    y = F.relu(batchnorm(sd, "model.bn1", y, bn_train))
+    y = act(batchnorm(sd, "model.bn1", y, bn_train))
     y = F.max_pool2d(y, 3, 2, 1, ceil_mode=True)
     for li, (planes, blocks, stride, dil) in enumerate(stages, start=1):
         for bi in range(blocks):
-            y = bottleneck(sd, "model.layer{}.{}".format(li, bi), y, stride if bi == 0 else 1, dil, bn_train)
+            y = bottleneck(sd, "model.layer{}.{}".format(li, bi), y, stride if bi == 0 else 1, dil, bn_train, act)
     return aspp_sum(sd, "model.layer5.conv2d_list", y)
 
 

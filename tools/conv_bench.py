@@ -48,19 +48,21 @@ for name, cin, cout, br, stride, H, W, cnt in SHAPES:
     OH, OW = spec.out_hw(H, W)
     dz = torch.randn(B, cout, OH, OW, device="cuda")
     flops = 2.0 * B * OH * OW * cout * spec.K
-    tab = ops.conv_table(spec, H, W, False, x.device)
-    pk = ops.conv_pack(spec, ws, False)
+    order = ops.gemm_order(spec, False)
+    tab = ops.conv_table(spec, H, W, False, x.device, order)
+    tabw = ops.conv_table(spec, H, W, False, x.device, 0)
+    pk = ops.conv_pack(spec, ws, False, order=order)
     y = torch.empty(B, cout, OH, OW, device="cuda")
     tf = timeit(lambda: ops.conv_gemm(x, pk, tab, y, (OH, OW), stride, cout, spec.K))
     line = "{:18s} fwd {:7.3f} ms {:6.1f} TF".format(name, tf * 1e3, flops / tf / 1e12)
     tot["fwd"][0] += flops * cnt; tot["fwd"][1] += tf * cnt
     if name != "stem7x7":
-        tabt = ops.conv_table(spec, OH, OW, True, x.device)
-        pkt = ops.conv_pack(spec, ws, True)
+        tabt = ops.conv_table(spec, OH, OW, True, x.device, ops.gemm_order(spec, True))
+        pkt = ops.conv_pack(spec, ws, True, order=ops.gemm_order(spec, True))
         td = timeit(lambda: ops.conv_dgrad(spec, dz, ws, (H, W), table=tabt, packed=pkt))
         line += " | dgrad {:7.3f} ms {:6.1f} TF".format(td * 1e3, flops / td / 1e12)
         tot["dgrad"][0] += flops * cnt; tot["dgrad"][1] += td * cnt
-    tw = timeit(lambda: ops.conv_wgrad(spec, dz, x, ws, table=tab))
+    tw = timeit(lambda: ops.conv_wgrad(spec, dz, x, ws, table=tabw))
     line += " | wgrad {:7.3f} ms {:6.1f} TF".format(tw * 1e3, flops / tw / 1e12)
     tot["wgrad"][0] += flops * cnt; tot["wgrad"][1] += tw * cnt
     print(line, flush=True)
