@@ -143,8 +143,11 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 2 : 3) void conv_gemm(const flo
     it = total * my_range / G;
     it_end = total * (my_range + 1) / G;
   } else {
-    const int n_tile = (slot / m_tiles) * kNumXcd + xcd;
-    if (n_tile >= n_tiles) return;
+    // each XCD owns a CONTIGUOUS run of pixel tiles (spatial neighbours share halo rows in its L2)
+    const int per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
+    const int n_local = slot / m_tiles;
+    const int n_tile = xcd * per_xcd + n_local;
+    if (n_local >= per_xcd || n_tile >= n_tiles) return;
     it = ((long long)n_tile * m_tiles + slot % m_tiles) * KT;
     it_end = it + KT;
   }
