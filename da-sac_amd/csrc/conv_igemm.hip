@@ -88,7 +88,7 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // them last); the other worker deposits its accumulators in `partial` as soon as it has them and raises
 // a flag (agent-scope release/acquire, placement independent).
 template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK>
-__global__ __launch_bounds__(kThreads, STREAMK ? 2 : 3) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
+__global__ __launch_bounds__(kThreads, 3) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
                                                       float* __restrict__ partial, int* __restrict__ flags) {
@@ -134,28 +134,28 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 2 : 3) void conv_gemm(const flo
   // go to the same XCD so that they share its L2.
   const int bid = blockIdx.x;
   const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
-  long long it, it_end;
+  int it, it_end;                                            // (tile, K-step) space: tiles*KT < 2^31 (checked by the host)
   int my_range = 0;
   if (STREAMK) {
     const int G = gridDim.x;                                 // multiple of 8
     my_range = xcd * (G / kNumXcd) + slot;
     const long long total = (long long)m_tiles * n_tiles * KT;
-    it = total * my_range / G;
-    it_end = total * (my_range + 1) / G;
+    it = (int)(total * my_range / G);
+    it_end = (int)(total * (my_range + 1) / G);
   } else {
     // each XCD owns a CONTIGUOUS run of pixel tiles (spatial neighbours share halo rows in its L2)
     const int per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
     const int n_local = slot / m_tiles;
     const int n_tile = xcd * per_xcd + n_local;
     if (n_local >= per_xcd || n_tile >= n_tiles) return;
-    it = ((long long)n_tile * m_tiles + slot % m_tiles) * KT;
+    it = (n_tile * m_tiles + slot % m_tiles) * KT;
     it_end = it + KT;
   }
 
   while (it < it_end) {
-    const int tile = (int)(it / KT);
-    const int ks = (int)(it - (long long)tile * KT);
-    const int ke = (int)min((long long)KT, ks + (it_end - it));
+    const int tile = it / KT;
+    const int ks = it - tile * KT;
+    const int ke = min(KT, ks + (it_end - it));
     it += ke - ks;
     const int m0 = (tile % m_tiles) * BM, n0 = (tile / m_tiles) * BN;
 
@@ -288,9 +288,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 2 : 3) void conv_gemm(const flo
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __hip_atomic_store(&flags[my_range], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        continue;
-      }
-      if (ke < KT) {
+      } else if (ke < KT) {
         // I hold the FIRST K-steps; the rest was deposited by the next range at the start of its work.
         if (t == 0) {
           int spins = 0;
@@ -318,6 +316,8 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 2 : 3) void conv_gemm(const flo
     // The BN scale is already folded into the packed weights.  All traffic goes through buffer
     // descriptors: per-lane voffset = pixel position (+ the lane-half's 4-row step), the row offset is
     // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
+    const bool deposited = STREAMK && ks > 0;                // this worker only contributed a partial sum
+    if (!deposited) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int pix = n0 + wn * WN + j * 32 + li;
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 2 : 3) void conv_gemm(const flo
           asm volatile("" ::: "memory");
         }
       }
+    }
     }
     if (STREAMK) __syncthreads();      // LDS is reused by the next tile of this worker
   }
@@ -682,8 +683,8 @@ static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, 
   return DASAC_OK;
 }
 
-constexpr int kSkWorkersPerCu = 2;                       // persistent 128x128 workers per CU
-constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 512, multiple of 8
+constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
+constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8
 
 // stream-K pays when the tile count leaves the last round of resident blocks (3 per CU for the plain
 // kernel) mostly empty
@@ -703,6 +704,7 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
                        const Epilogue& ep, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
   const int n_tiles = (g.Npix + BN - 1) / BN;
+  if ((long long)m_tiles * (n_tiles + kNumXcd) * (g.Kpad / BK) >= (1ll << 31)) return fail(DASAC_EINVAL, "conv_gemm: iteration space exceeds 2^31");
   if (BM == 128 && workspace && want_streamk(m_tiles * n_tiles, g.Kpad / BK)) {
     const size_t part_bytes = (size_t)kSkWorkers * (BM * BN) * sizeof(float);
     const size_t need = part_bytes + (size_t)(kSkWorkers + 1) * sizeof(int);
