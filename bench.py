@@ -25,10 +25,15 @@ import torch.nn as nn
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
-def model_cfg():
+def model_cfg(arch="deeplabv2_resnet101", baseline=False):
     from types import SimpleNamespace as NS
-    # core/config.py:130-159 + configs/deeplabv2_resnet101_train.yaml
-    return NS(ARCH="deeplabv2_resnet101", INIT_MODEL="", BASELINE=False, LR=2.5e-4, LR_TARGET=5.0, WEIGHT_DECAY=5e-4,
+    # core/config.py:130-159 + configs/deeplabv2_resnet101_train.yaml (fcn_vgg16_train.yaml: LR 5e-4, LR_TARGET 2)
+    if arch == "fcn_vgg16_bn":
+        return NS(ARCH=arch, INIT_MODEL="", BASELINE=baseline, LR=5e-4, LR_TARGET=2.0, WEIGHT_DECAY=5e-4,
+                  MOMENTUM=0.9, OPT_NESTEROV=False, STAT_MOMENTUM=0.99, NET_MOMENTUM=0.99, NET_MOMENTUM_ITER=100,
+                  CONF_DISCOUNT=True, CONF_POOL_ON=True, CONF_POOL="avg_pool", FOCAL_P=3, LOSS="focal_ce_conf",
+                  RUN_CONF_UPPER=0.75, RUN_CONF_LOWER=0.2, THRESHOLD_BETA=1e-3)
+    return NS(ARCH=arch, INIT_MODEL="", BASELINE=baseline, LR=2.5e-4, LR_TARGET=5.0, WEIGHT_DECAY=5e-4,
               MOMENTUM=0.9, OPT_NESTEROV=False, STAT_MOMENTUM=0.99, NET_MOMENTUM=0.99, NET_MOMENTUM_ITER=100,
               CONF_DISCOUNT=True, CONF_POOL_ON=True, CONF_POOL="avg_pool", FOCAL_P=3, LOSS="focal_ce_conf",
               RUN_CONF_UPPER=0.75, RUN_CONF_LOWER=0.2, THRESHOLD_BETA=1e-3)
@@ -69,7 +74,15 @@ def main():
     ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"],
+                    help="cfg3 (default, the headline): RN101+SAC 8+2x4 crops @769^2; cfg2: RN101 baseline/AdaBN step, 2 source + 2 "
+                         "target crops @769^2, train-mode BN; cfg5: VGG16-FCN8s + SAC @512x1024 (per-GPU 8 + 2x4 crops)")
     args = ap.parse_args()
+    arch, baseline, hw = "deeplabv2_resnet101", False, (args.size, args.size)
+    if args.config == "cfg2":
+        baseline, args.batch, args.groups, args.views = True, 2, 2, 1
+    elif args.config == "cfg5":
+        arch, hw = "fcn_vgg16_bn", (512, 1024)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,19 +98,25 @@ def main():
     import driver
     from dasac_hip import ops
 
-    cfg = model_cfg()
+    cfg = model_cfg(arch, baseline)
     if rank != 0:
         sys.stdout = open(os.devnull, "w")
     net = models.get_model(cfg, local, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
     driver.init_synthetic_weights(net, seed=0)
     net.cuda(local).train()
-    net.running_conf.fill_(0.05)
+    if not baseline:
+        net.running_conf.fill_(0.05)
     optim = driver.make_optimizer(net, cfg)
     step_net = nn.parallel.DistributedDataParallel(net, device_ids=[local]) if world > 1 else net
-    src, tgt = driver.synthetic_batches(args.batch, args.groups, args.views, (args.size, args.size), dev, seed=rank)
+    src, tgt = driver.synthetic_batches(args.batch, args.groups, args.views, hw, dev, seed=rank)
+    if arch != "deeplabv2_resnet101":
+        driver.calibrate_classifier(net, src[0][:1])          # logits std ~3 whatever the backbone's feature scale
     src = (src[0], driver.self_consistent_labels(net, src[0]))
 
     def step(i):
+        if baseline:      # train.py:274-289: source fwd/bwd/step + no-grad train-mode target forward (AdaBN)
+            l = driver.baseline_train_iteration(step_net, optim, src, tgt[0])
+            return None, l, None
         tgt_i = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])      # forward rewrites -1 -> 255 in place
         return driver.sac_train_iteration(step_net, optim, src, tgt_i, args.views, update_teacher=(i == 0),
                                           lr_target=cfg.LR_TARGET)
@@ -122,7 +141,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     losses = {k: float(v.detach().mean()) for k, v in out[1].items()}
-    labelled = float((out[2]["teacher_labels"] != 255).float().mean())
+    labelled = float((out[2]["teacher_labels"] != 255).float().mean()) if out[2] is not None else 0.0
 
     if rank == 0:
         sys.stdout = sys.__stdout__
@@ -139,8 +158,12 @@ def main():
             "value": round(world * args.batch * args.steps / dt, 4), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg-3: RN101-DeepLabv2 + SAC, per GPU {} source + {}x{} target crops @{}x{}, frozen BN, "
-                                   "random-init weights".format(args.batch, args.groups, args.views, args.size, args.size),
+            "config": {"workload": {"cfg3": "cfg-3: RN101-DeepLabv2 + SAC, per GPU {} source + {}x{} target crops @{}x{}, frozen BN, "
+                                            "random-init weights",
+                                    "cfg2": "cfg-2: RN101-DeepLabv2 baseline/AdaBN step, per GPU {} source crops fwd+bwd+SGD + {}x{} target "
+                                            "crops no-grad train-mode fwd @{}x{}, batch-statistics BN, random-init weights",
+                                    "cfg5": "cfg-5: VGG16-FCN8s + SAC, per GPU {} source + {}x{} target crops @{}x{}, frozen BN, Dropout2d "
+                                            "p=0.1, random-init weights"}[args.config].format(args.batch, args.groups, args.views, hw[0], hw[1]),
                        "global_batch": world * args.batch, "crops_per_step": world * (args.batch + args.groups * args.views),
                        "parallelism": "dp{}".format(world)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -150,9 +173,10 @@ def main():
                          "launches": dom["launches"], "avg_launch_ms": round(dom["seconds"] / max(dom["launches"], 1) * 1e3, 4)},
             "kernels": {k: {"tflops": round(v["flops"] / max(v["seconds"], 1e-12) / 1e12, 2), "ms_per_step": round(v["seconds"] / args.steps * 1e3, 2),
                             "launches_per_step": v["launches"] // args.steps} for k, v in prof.items()},
-            "check": {"self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"), "labelled_frac": round(labelled, 4)},
+            "check": {"loss_ce": losses.get("loss_ce"), "self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"),
+                      "labelled_frac": round(labelled, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
             line["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(line))
     if world > 1:

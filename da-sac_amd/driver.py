@@ -140,3 +140,26 @@ def self_consistent_labels(net, images, border=16):
     ys[:, :, :border] = 255
     ys[:, :, -border:] = 255
     return ys
+
+
+def _classifier_layers(core):
+    import torch.nn as nn
+    return [m for n, m in core.named_modules()
+            if isinstance(m, nn.Conv2d) and ("conv2d_list" in n or n.startswith(("score_pool", "vgg_head.8")))]
+
+
+def calibrate_classifier(net, image, target_std=3.0):
+    """Rescales the (linear) classifier layers of a synthetic-weight net so that its stride-8 logits have the given
+    standard deviation on `image` -- peaked but unsaturated softmax whatever the backbone's feature scale is."""
+    core = net.backbone if hasattr(net, "backbone") else net
+    was = core.training
+    core.eval()
+    with torch.no_grad():
+        std = float(core(image)[0].std())
+        f = target_std / max(std, 1e-12)
+        for m in _classifier_layers(core):
+            m.weight.mul_(f)
+            if m.bias is not None:
+                m.bias.mul_(f)
+    core.train(was)
+    return f
