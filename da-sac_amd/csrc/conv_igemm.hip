@@ -88,7 +88,7 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // them last); the other worker deposits its accumulators in `partial` as soon as it has them and raises
 // a flag (agent-scope release/acquire, placement independent).
 template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK>
-__global__ __launch_bounds__(kThreads, 3) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
+__global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
                                                       float* __restrict__ partial, int* __restrict__ flags) {
