@@ -391,7 +391,7 @@ constexpr int kWgPitch = 33;
 // per block, the per-row part of both operand addresses is a scalar offset, the pixel position is
 // advanced incrementally (no divisions in the loop) -> ~25 VALU per 64 MFMAs.
 template <int BM, int BN, int WAVES_M, bool FAST>
-__global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
+__global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
                                                        float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
                                                        int pix_per_split) {
@@ -400,8 +400,10 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_LOADS = BM / 8, B_LOADS = BN / 8;      // 8 rows of 32 pixels per pass of 256 threads
 
-  __shared__ float sA[2][BM * kWgPitch];
-  __shared__ float sB[2][BN * kWgPitch];
+  // ONE LDS stage (34 KB for the 128x128 tile -> 4 blocks per CU); the next tile waits in registers while the
+  // MFMAs run, two barriers per step.  More co-resident blocks hide the extra barrier (measured).
+  __shared__ float sA[1][BM * kWgPitch];
+  __shared__ float sB[1][BN * kWgPitch];
 
   const int tile = blockIdx.x % (m_tiles * k_tiles), split = blockIdx.x / (m_tiles * k_tiles);
   const int m_tile = tile % m_tiles, k_tile = tile / m_tiles;
@@ -504,10 +506,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
   }
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
-    const int buf = s & 1;
     if (s + 1 < steps) DASAC_WG_LOAD();
-    const float* a_base = &sA[buf][(wm * WM + li) * kWgPitch + lh];
-    const float* b_base = &sB[buf][(wn * WN + li) * kWgPitch + lh];
+    const float* a_base = &sA[0][(wm * WM + li) * kWgPitch + lh];
+    const float* b_base = &sB[0][(wn * WN + li) * kWgPitch + lh];
 #pragma unroll
     for (int kk = 0; kk < kWgPix / 2; ++kk) {
       float a[TM], b[TN];
@@ -520,8 +521,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < steps) DASAC_WG_STORE(buf ^ 1);
     __syncthreads();
+    if (s + 1 < steps) {
+      DASAC_WG_STORE(0);
+      __syncthreads();
+    }
   }
 #undef DASAC_WG_LOAD
 #undef DASAC_WG_STORE
@@ -828,7 +832,7 @@ static int wgrad_bn(int Cx) { return (Cx % 128 != 0 && Cx % 64 == 0) ? 64 : 128;
 
 static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM, int BNk = 128) {
   const int tiles = (Mpad / BM) * (Kpad / BNk);
-  const int slots = kNumCu * (BM == 128 ? 2 : 3);
+  const int slots = kNumCu * 3;
   int max_splits = (Npix + 1023) / 1024;                    // at least 1024 pixels per split
   if (max_splits > 64) max_splits = 64;
   if (max_splits < 1) max_splits = 1;
