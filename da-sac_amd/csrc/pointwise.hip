@@ -444,3 +444,54 @@ extern "C" int dasac_bn_bwd_apply(const float* dy, const float* z, const float* 
   }
   return DASAC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Validation counts: utils/metrics.py:9-53 `Jaccard.add_sample` + the argmax of
+// train.py:339-469 -- per-class true-positive / false-positive / false-negative pixel counts from the
+// upsampled logits in ONE pass (the reference loops over the 19 classes with .item() syncs per batch).
+// ------------------------------------------------------------------------------------------------
+namespace dasac {
+
+__global__ __launch_bounds__(256) void iou_counts(const float* __restrict__ logits, const int64_t* __restrict__ gt, int C,
+                                                  int64_t HW, int64_t total, int ignore_index,
+                                                  unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int s[3 * 64];
+  for (int i = threadIdx.x; i < 3 * 64; i += 256) s[i] = 0;
+  __syncthreads();
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+    const int64_t b = p / HW, r = p - b * HW;
+    const int64_t y = gt[p];
+    if (y == ignore_index || y < 0 || y >= C) continue;
+    const float* lp = logits + b * C * HW + r;
+    float best = lp[0];
+    int k = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = lp[(int64_t)c * HW];
+      if (v > best) {
+        best = v;
+        k = c;
+      }
+    }
+    if (k == (int)y) {
+      atomicAdd(&s[k], 1u);                 // tp
+    } else {
+      atomicAdd(&s[64 + k], 1u);            // fp of the predicted class
+      atomicAdd(&s[128 + (int)y], 1u);      // fn of the true class
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * 64; i += 256)
+    if (s[i] && (i & 63) < C) atomicAdd(&counts[(i >> 6) * C + (i & 63)], (unsigned long long)s[i]);
+}
+
+}  // namespace dasac
+
+extern "C" int dasac_iou_counts(const float* logits, const int64_t* gt, int B, int C, int64_t HW, int ignore_index,
+                                int64_t* counts, dasac_stream_t stream) {
+  DASAC_REQUIRE(logits && gt && counts && B > 0 && C > 0 && C <= 64 && HW > 0, "iou_counts: bad arguments");
+  const int64_t total = (int64_t)B * HW;
+  hipLaunchKernelGGL(iou_counts, dim3(stream_grid(total, 256, kNumCu * 8)), dim3(256), 0, as_stream(stream), logits, gt, C, HW, total,
+                     ignore_index, reinterpret_cast<unsigned long long*>(counts));
+  DASAC_CHECK_LAUNCH("iou_counts");
+  return DASAC_OK;
+}

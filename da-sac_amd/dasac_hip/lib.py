@@ -53,6 +53,7 @@ PROTOTYPES = {
     "dasac_tap_gather": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     "dasac_tap_scatter": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_conv_wgrad_finish_expanded": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "dasac_iou_counts": (_i, [_p, _p, _i, _i, _l, _i, _p, _p]),
     "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

@@ -607,3 +607,16 @@ class ExpandedConv:
         H, W = in_hw
         dx = torch.empty((B, self.spec.cin, H, W), dtype=torch.float32, device=d.device)
         return conv_gemm(d, packed_t, table_t, dx, (H, W), 1, self.spec.cin, self.E, 1, None, res, mask, False)
+
+
+def iou_counts(logits_up, gt, counts=None, ignore_index=255):
+    """Accumulates per-class (tp, fp, fn) pixel counts of argmax(logits_up) vs gt into `counts` (int64 [3,C])."""
+    lib = L.load()
+    L.require_gpu(logits_up, gt)
+    logits_up, gt = _c(logits_up), _c(gt)
+    B, Cn, H, W = logits_up.shape
+    if counts is None:
+        counts = torch.zeros((3, Cn), dtype=torch.int64, device=logits_up.device)
+    L.check(lib.dasac_iou_counts(logits_up.data_ptr(), gt.data_ptr(), B, Cn, H * W, int(ignore_index), counts.data_ptr(),
+                                 L.stream_ptr()), "dasac_iou_counts")
+    return counts

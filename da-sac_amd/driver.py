@@ -163,3 +163,47 @@ def calibrate_classifier(net, image, target_std=3.0):
                 m.bias.mul_(f)
     core.train(was)
     return f
+
+
+# --------------------------------------------------------------------------------------------------
+# checkpoints and validation
+# --------------------------------------------------------------------------------------------------
+def save_checkpoint(path, net, optim, score, epoch):
+    """File layout of the reference's utils/checkpoints.py:62-74: {"model": state dict with the DDP
+    "module." prefix, "opt": optimiser state, "score", "epoch"}."""
+    core = net.module if hasattr(net, "module") else net
+    model = {"module." + k: v for k, v in core.state_dict().items()}
+    torch.save({"model": model, "opt": optim.state_dict() if optim is not None else None, "score": score, "epoch": epoch}, path)
+
+
+def load_checkpoint(path, net, optim=None, map_location="cpu"):
+    """utils/checkpoints.py:49-60: strict=False, so a baseline snapshot (backbone only) loads into SAC and
+    leaves the teacher / class prior to the first `_momentum_update`.  Accepts keys with or without "module."."""
+    blob = torch.load(path, map_location=map_location)
+    core = net.module if hasattr(net, "module") else net
+    model = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in blob["model"].items()}
+    missing, unexpected = core.load_state_dict(model, strict=False)
+    if optim is not None and blob.get("opt") is not None:
+        optim.load_state_dict(blob["opt"])
+    return blob.get("epoch", 0), blob.get("score", 0.0), missing, unexpected
+
+
+def validation_iou(net, batches, num_classes=19):
+    """mIoU over (image, label) batches: argmax + per-class tp/fp/fn in one kernel pass per batch
+    (train.py:339-469, utils/metrics.py:9-53); counts are all-reduced when a process group exists."""
+    import torch.distributed as dist
+    from dasac_hip import ops
+    core = net.module if hasattr(net, "module") else net
+    was = core.training
+    core.eval()
+    counts = None
+    with torch.no_grad():
+        for image, gt in batches:
+            _, logits_up = core(image)
+            counts = ops.iou_counts(logits_up, gt, counts)
+    core.train(was)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counts)
+    tp, fp, fn = counts[0].double(), counts[1].double(), counts[2].double()
+    iou = tp / (tp + fp + fn).clamp_min(1.0)
+    return float(iou.mean()), iou

@@ -222,6 +222,12 @@ int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const
                        const float* gamma, const double* sums, double count, int N, int C, int64_t HW,
                        float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);
 
+/* Validation counts (utils/metrics.py:9-53, train.py:339-469): counts[0:C] += tp, counts[C:2C] += fp,
+ * counts[2C:3C] += fn of argmax_c logits vs gt (pixels with gt == ignore_index skipped); the caller
+ * zeroes `counts` (int64 [3*C]) once per evaluation and all-reduces it across ranks. */
+int dasac_iou_counts(const float* logits, const int64_t* gt, int B, int C, int64_t HW, int ignore_index,
+                     int64_t* counts, dasac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
