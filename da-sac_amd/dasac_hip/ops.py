@@ -20,25 +20,26 @@ class _Profile:
     def start(self):
         self.on, self.records = True, []
 
-    def stop(self):
+    def stop(self, by_shape=False):
+        """Per-kernel-class totals; by_shape=True keys on (class, shape tag) instead (tools/step_shapes.py)."""
         self.on = False
         torch.cuda.synchronize()
         out = {}
-        for name, flops, a, b in self.records:
-            d = out.setdefault(name, {"flops": 0.0, "seconds": 0.0, "launches": 0})
+        for name, flops, a, b, tag in self.records:
+            d = out.setdefault((name, tag) if by_shape else name, {"flops": 0.0, "seconds": 0.0, "launches": 0})
             d["flops"] += flops
             d["seconds"] += a.elapsed_time(b) * 1e-3
             d["launches"] += 1
         self.records = []
         return out
 
-    def span(self, name, flops):
-        return _Span(self, name, flops) if self.on else _NULL
+    def span(self, name, flops, tag=None):
+        return _Span(self, name, flops, tag) if self.on else _NULL
 
 
 class _Span:
-    def __init__(self, prof, name, flops):
-        self.prof, self.name, self.flops = prof, name, flops
+    def __init__(self, prof, name, flops, tag):
+        self.prof, self.name, self.flops, self.tag = prof, name, flops, tag
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -47,7 +48,7 @@ class _Span:
     def __exit__(self, *exc):
         b = torch.cuda.Event(enable_timing=True)
         b.record()
-        self.prof.records.append((self.name, self.flops, self.a, b))
+        self.prof.records.append((self.name, self.flops, self.a, b, self.tag))
 
 
 class _Null:
@@ -156,7 +157,7 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     span = "conv_gemm"
     if PROFILE.on:
         span = "conv_gemm<stream-K>" if lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K) else "conv_gemm<tile-per-block>"
-    with PROFILE.span(span, 2.0 * Nb * OH * OW * M * K):
+    with PROFILE.span(span, 2.0 * Nb * OH * OW * M * K, (M, K, Nb * OH * OW, stride, ostride, res is not None, mask is not None)):
         L.check(lib.dasac_conv_gemm(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
                                     stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
                                     L.ptr(mask), int(relu), L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr()),
@@ -208,7 +209,7 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=No
     table = conv_table(spec, H, W, False, x.device) if table is None else table
     nbytes = lib.dasac_conv_wgrad_workspace(Nb, OH, OW, M, spec.K)
     ws = L.workspace(nbytes, x.device)
-    with PROFILE.span("conv_wgrad", 2.0 * Nb * OH * OW * M * spec.K):
+    with PROFILE.span("conv_wgrad", 2.0 * Nb * OH * OW * M * spec.K, (M, spec.K, Nb * OH * OW, spec.stride, 1, False, False)):
         L.check(lib.dasac_conv_wgrad(_c(dz).data_ptr(), x.data_ptr(), table.data_ptr(), Nb, Cx, H, W, OH, OW, spec.stride, M,
                                      spec.K, ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
     grads, tap0 = [], 0
@@ -589,7 +590,7 @@ class ExpandedConv:
         B, Cx, H, W = x.shape
         nbytes = lib.dasac_conv_wgrad_workspace(B, H, W, self.E, self.spec.cin)
         ws = L.workspace(nbytes, x.device)
-        with PROFILE.span("conv_wgrad", 2.0 * B * H * W * self.E * self.spec.cin):
+        with PROFILE.span("conv_wgrad", 2.0 * B * H * W * self.E * self.spec.cin, (self.E, self.spec.cin, B * H * W, 1, 1, False, False)):
             L.check(lib.dasac_conv_wgrad(d.data_ptr(), x.data_ptr(), table.data_ptr(), B, Cx, H, W, H, W, 1, self.E, self.spec.cin,
                                          ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
         grads, tap0 = [], 0
