@@ -23,6 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: dense bf16 matrix peak; a split-bf16 product costs three MFMAs
 
 
 def model_cfg(arch="deeplabv2_resnet101", baseline=False):
@@ -74,6 +75,10 @@ def main():
     ap.add_argument("--groups", type=int, default=2)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="arithmetic of the forward/data-gradient GEMMs for the headline number: exact fp32 MFMA (default) or the "
+                         "split-bf16 path (3 bf16 MFMAs per product, fp32 accumulate)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-by-the-contract) run in the other precision")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"],
                     help="cfg3 (default, the headline): RN101+SAC 8+2x4 crops @769^2; cfg2: RN101 baseline/AdaBN step, 2 source + 2 "
                          "target crops @769^2, train-mode BN; cfg5: VGG16-FCN8s + SAC @512x1024 (per-GPU 8 + 2x4 crops)")
@@ -126,20 +131,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    ops.PROFILE.start()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    prof = ops.PROFILE.stop()
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    def measure(first, warmup):
+        """`warmup` untimed steps, then exactly args.steps timed ones between fences; max over ranks."""
+        for i in range(warmup):
+            step(first + i)
+        fence()
+        ops.PROFILE.start()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            res = step(first + warmup + i)
+        fence()
+        dt_ = time.perf_counter() - t0
+        prof_ = ops.PROFILE.stop()
+        if world > 1:
+            tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax)
+        return dt_, prof_, res
+
+    def kernel_table(prof_):
+        return {k: {"tflops": round(v["flops"] / max(v["seconds"], 1e-12) / 1e12, 2), "ms_per_step": round(v["seconds"] / args.steps * 1e3, 2),
+                    "launches_per_step": v["launches"] // args.steps} for k, v in prof_.items()}
+
+    ops.set_precision(args.precision)
+    dt, prof, out = measure(0, args.warmup)
+    alt = None
+    if not args.no_alt and not baseline:
+        # the same K steps once more in the other arithmetic (outside the contract's timed region; reported as "alt")
+        other = "bf16x3" if args.precision == "fp32" else "fp32"
+        ops.set_precision(other)
+        dt2, prof2, _ = measure(args.warmup + args.steps, 1)
+        ops.set_precision(args.precision)
+        alt = {"dtype": other, "value": round(world * args.batch * args.steps / dt2, 4), "unit": "images/sec",
+               "ms_per_step": round(dt2 / args.steps * 1e3, 3), "kernels": kernel_table(prof2),
+               "note": "same step with the forward/data-gradient GEMMs in {} arithmetic; weight gradient and everything else "
+                       "unchanged".format("split-bf16 (3 bf16 MFMAs per product, fp32 accumulate; tests/test_gpu_bf16x3.py)"
+                                          if other == "bf16x3" else "exact fp32 MFMA")}
     losses = {k: float(v.detach().mean()) for k, v in out[1].items()}
     labelled = float((out[2]["teacher_labels"] != 255).float().mean()) if out[2] is not None else 0.0
 
@@ -149,6 +176,7 @@ def main():
         dom_name = max(gemm, key=lambda k: gemm[k]["seconds"]) if gemm else "conv_gemm"
         dom = gemm.get(dom_name, {"flops": 0.0, "seconds": 1.0, "launches": 0})
         ach = dom["flops"] / max(dom["seconds"], 1e-12) / 1e12
+        peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-measured HBM bytes per launch (separate rocprofv3 passes)
         if os.path.isfile(tfile):
@@ -157,7 +185,9 @@ def main():
             "metric": "train images/sec (769x769, 19-cls, RN101 DeepLabv2, K=3)",
             "value": round(world * args.batch * args.steps / dt, 4), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 operands split into bf16 head+tail, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": {"cfg3": "cfg-3: RN101-DeepLabv2 + SAC, per GPU {} source + {}x{} target crops @{}x{}, frozen BN, "
                                             "random-init weights",
                                     "cfg2": "cfg-2: RN101-DeepLabv2 baseline/AdaBN step, per GPU {} source crops fwd+bwd+SGD + {}x{} target "
@@ -166,16 +196,18 @@ def main():
                                             "p=0.1, random-init weights"}[args.config].format(args.batch, args.groups, args.views, hw[0], hw[1]),
                        "global_batch": world * args.batch, "crops_per_step": world * (args.batch + args.groups * args.views),
                        "parallelism": "dp{}".format(world)},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "dasac::" + dom_name + " (forward + data-gradient implicit GEMM, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": traffic,
+                         "kernel": "dasac::" + dom_name + " (forward + data-gradient implicit GEMM, {})".format(
+                             "fp32 MFMA" if args.precision == "fp32" else "3 bf16 MFMAs per fp32 product: peak = bf16 peak / 3"),
                          "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                          "launches": dom["launches"], "avg_launch_ms": round(dom["seconds"] / max(dom["launches"], 1) * 1e3, 4)},
-            "kernels": {k: {"tflops": round(v["flops"] / max(v["seconds"], 1e-12) / 1e12, 2), "ms_per_step": round(v["seconds"] / args.steps * 1e3, 2),
-                            "launches_per_step": v["launches"] // args.steps} for k, v in prof.items()},
+            "kernels": kernel_table(prof),
             "check": {"loss_ce": losses.get("loss_ce"), "self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"),
                       "labelled_frac": round(labelled, 4)},
         }
+        if alt is not None:
+            line["alt"] = alt
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
             line["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(line))

@@ -72,6 +72,26 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
   return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
 
+// Split-bf16 ("bf16x3") operands: x = head + tail with head = bf16(x) (round to nearest even) and
+// tail = bf16(x - head); eight consecutive k values of one row / pixel make one 16-byte MFMA operand.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 as_bf16x8(f32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {          // v_cvt_pk_bf16_f32, a in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ void split_bf16(f32x4 v0, f32x4 v1, f32x4& heads, f32x4& tails) {
+  const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const unsigned h = pack_bf16(v[2 * p], v[2 * p + 1]);
+    const float t0 = v[2 * p] - __uint_as_float(h << 16), t1 = v[2 * p + 1] - __uint_as_float(h & 0xffff0000u);   // exact
+    heads[p] = __uint_as_float(h);
+    tails[p] = __uint_as_float(pack_bf16(t0, t1));
+  }
+}
+
 // LDS tiles are k-interleaved: element (k, x) of a K-step lives at [(k/4)][x][k%4], so that
 //   * the packed weights (stored the same way in HBM, see pack_weights) move global->LDS as 16-byte words,
 //   * a thread that gathered 4 consecutive k rows of one pixel stores them with one ds_write_b128,
@@ -87,7 +107,7 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // work).  A tile cut by a range boundary is finished by the worker holding its FIRST K-steps (it reaches
 // them last); the other worker deposits its accumulators in `partial` as soon as it has them and raises
 // a flag (agent-scope release/acquire, placement independent).
-template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK>
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3>
 __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
@@ -102,6 +122,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
   constexpr int B_QUADS = KQ / B_Q_PASS;                     // quads (of 4 rows) gathered per thread
   constexpr int ACC_REGS = TM * TN * 16;
   static_assert(TM >= 1 && TN >= 1 && BN <= kThreads && KQ % B_Q_PASS == 0, "tile shape");
+  static_assert(!X3 || (BK == 16 && BN == 128), "split-bf16 path: one 16-deep MFMA block per K-step, a k octet per thread");
 
   __shared__ f32x4 sA[2][KQ * BM];
   __shared__ f32x4 sB[2][KQ * BN];
@@ -198,14 +219,15 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
       const bool ok = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);               \
       const unsigned voff = ok ? (unsigned)(pixbase + (e.x - e.w)) * 4u : kPoison;                   \
       _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                          \
-        const int row0 = 4 * (bq0 + r * B_Q_PASS);                                                   \
+        const int row0 = X3 ? 8 * bq0 + 4 * r : 4 * (bq0 + r * B_Q_PASS);                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
           rb[r][j] = buf_f32(rx, voff, (e.w + (row0 + j) * planeHW) * 4);                            \
       }                                                                                              \
     } else {                                                                                         \
       int4 te[B_QUADS * 4]; /* all table rows of this K-step first: one batch of scalar loads */     \
       _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r)                                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) te[r * 4 + j] = tab[((kt) * KQ + bq0 + r * B_Q_PASS) * 4 + j]; \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+          te[r * 4 + j] = tab[(kt) * BK + (X3 ? 8 * bq0 + 4 * r : 4 * (bq0 + r * B_Q_PASS)) + j];    \
       _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                          \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
           const int4 e = te[r * 4 + j];                                                              \
@@ -222,7 +244,14 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
       const int v = t + i * kThreads;                                                                \
       if (A_VEC % kThreads == 0 || v < A_VEC) sA[buf][v] = ra[i];                                    \
     }                                                                                                \
-    _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) sB[buf][(bq0 + r * B_Q_PASS) * BN + bcol] = rb[r]; \
+    if (X3) {                                                                                        \
+      f32x4 hi, lo;                                                                                  \
+      split_bf16(rb[0], rb[B_QUADS - 1], hi, lo);                                                    \
+      sB[buf][(2 * bq0) * BN + bcol] = hi;                                                           \
+      sB[buf][(2 * bq0 + 1) * BN + bcol] = lo;                                                       \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) sB[buf][(bq0 + r * B_Q_PASS) * BN + bcol] = rb[r]; \
+    }                                                                                                \
   }
 
     f32x16 acc[TM][TN];
@@ -241,6 +270,25 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
       const bool more = kt + 1 < ke;
       if (more) DASAC_LOAD_TILE(kt + 1);
       f32x4 a4[BK / 8][TM], b4[BK / 8][TN];
+      if (X3) {
+        // quad slot q of the tile = (k octet lh, half h): h = 0 the bf16 heads, h = 1 the bf16 tails
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a4[h][i] = sA[buf][(2 * lh + h) * BM + wm * WM + i * 32 + li];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b4[h][j] = sB[buf][(2 * lh + h) * BN + wn * WN + j * 32 + li];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            // x*y ~ xl*yh + xh*yl + xh*yh (the tail*tail term is below 2^-16 of the product), fp32 accumulate
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a4[1][i]), as_bf16x8(b4[0][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a4[0][i]), as_bf16x8(b4[1][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a4[0][i]), as_bf16x8(b4[0][j]), acc[i][j], 0, 0, 0);
+          }
+      } else {
 #pragma unroll
       for (int gq = 0; gq < BK / 8; ++gq) {
         const int q = 2 * gq + lh;
@@ -260,6 +308,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].z, b4[gq][j].z, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].w, b4[gq][j].w, acc[i][j], 0, 0, 0);
           }
+      }
       }
       if (more) DASAC_STORE_TILE(buf ^ 1);
       __syncthreads();
@@ -629,6 +678,21 @@ __global__ void pack_weights(const float* __restrict__ Wt, const float* __restri
   }
 }
 
+// fp32 packed weights [(k/4)][Mpad][4] -> split-bf16 operands: K-step t (16 k) holds four slots of Mpad
+// 16-byte words, slot 2*o + h = octet o (k = 16t + 8o .. +7), h = 0 heads / 1 tails -- the same addressing
+// as the fp32 tile (slot == quad), so conv_gemm's weight path is shared.
+__global__ void pack_x3(const f32x4* Wp, f32x4* Wx, int Mpad, int Kpad) {   // Wx may alias Wp (in-place conversion)
+  const int64_t total = (int64_t)(Kpad / 8) * Mpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t oct = i / Mpad;                  // global octet index = 2*t + o
+    const int m = (int)(i - oct * Mpad);
+    f32x4 heads, tails;
+    split_bf16(Wp[(2 * oct) * Mpad + m], Wp[(2 * oct + 1) * Mpad + m], heads, tails);
+    Wx[(2 * oct) * Mpad + m] = heads;
+    Wx[(2 * oct + 1) * Mpad + m] = tails;
+  }
+}
+
 // dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G)
 // grid (chunks of 1024 k, output channels); the dot term is combined with one float atomic per block.
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P, const float* __restrict__ Psum, int splits,
@@ -703,7 +767,7 @@ static bool want_streamk(int tiles, int k_steps) {
   return k_steps >= 64 && (double)tiles / ((double)rounds * resident) < 0.93;
 }
 
-template <int BM, int BN, int WAVES_M, int BK, bool FAST>
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool X3 = false>
 static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
                        const Epilogue& ep, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
@@ -716,12 +780,12 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
     float* partial = reinterpret_cast<float*>(workspace);
     int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
     DASAC_HIP(hipMemsetAsync(flags, 0, (size_t)(kSkWorkers + 1) * sizeof(int), s));
-    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g, ep,
+    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g, ep,
                        m_tiles, n_tiles, partial, flags);
     return DASAC_OK;
   }
   const int n_tiles_pad = (n_tiles + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab,
+  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false, X3>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab,
                      Out, g, ep, m_tiles, n_tiles, nullptr, nullptr);
   return DASAC_OK;
 }
@@ -792,10 +856,10 @@ extern "C" size_t dasac_conv_gemm_workspace(void) {
   return (size_t)kSkWorkers * 128 * 128 * sizeof(float) + (size_t)(kSkWorkers + 1) * sizeof(int);
 }
 
-extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx,
-                               int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
-                               const float* shift, const float* res, const float* mask, int relu,
-                               void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+static int conv_gemm_impl(bool x3, const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx, int H,
+                          int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride, const float* shift,
+                          const float* res, const float* mask, int relu, void* workspace, size_t ws_bytes,
+                          dasac_stream_t stream) {
   DASAC_REQUIRE(x && packed && table && out, "conv_gemm: null pointer");
   GemmGeom g;
   const int Mpad = dasac_conv_mpad(M), Kloop = (K + kBK - 1) / kBK * kBK;   // table/pack are padded to 128 >= Kloop
@@ -807,7 +871,20 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
   const int4* tab = reinterpret_cast<const int4*>(table);
   hipStream_t s = as_stream(stream);
   const bool fast = Cx % kBK == 0;      // a K-step never straddles two taps
-  switch (pick_bm(Mpad)) {
+  const int bm = pick_bm(Mpad);
+  if (x3) {
+    DASAC_REQUIRE(bm >= 64, "conv_gemm_x3: needs M > 32 (use dasac_conv_gemm for skinny outputs)");
+    if (bm == 128)
+      rc = fast ? launch_gemm<128, 128, 2, kBK, true, true>(x, packed, tab, out, g, ep, workspace, ws_bytes, s)
+                : launch_gemm<128, 128, 2, kBK, false, true>(x, packed, tab, out, g, ep, workspace, ws_bytes, s);
+    else
+      rc = fast ? launch_gemm<64, 128, 2, kBK, true, true>(x, packed, tab, out, g, ep, nullptr, 0, s)
+                : launch_gemm<64, 128, 2, kBK, false, true>(x, packed, tab, out, g, ep, nullptr, 0, s);
+    if (rc) return rc;
+    DASAC_CHECK_LAUNCH("conv_gemm_x3");
+    return DASAC_OK;
+  }
+  switch (bm) {
     case 128:
       rc = fast ? launch_gemm<128, 128, 2, kBK, true>(x, packed, tab, out, g, ep, workspace, ws_bytes, s)
                 : launch_gemm<128, 128, 2, kBK, false>(x, packed, tab, out, g, ep, workspace, ws_bytes, s);
@@ -823,6 +900,31 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
   }
   if (rc) return rc;
   DASAC_CHECK_LAUNCH("conv_gemm");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx,
+                               int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
+                               const float* shift, const float* res, const float* mask, int relu,
+                               void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  return conv_gemm_impl(false, x, packed, table, out, Nb, Cx, H, W, OH, OW, stride, M, K, OutH, OutW, ostride, shift, res, mask,
+                        relu, workspace, ws_bytes, stream);
+}
+
+extern "C" int dasac_conv_gemm_x3(const float* x, const void* packed_x3, const int32_t* table, float* out, int Nb, int Cx,
+                                  int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
+                                  const float* shift, const float* res, const float* mask, int relu,
+                                  void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  return conv_gemm_impl(true, x, reinterpret_cast<const float*>(packed_x3), table, out, Nb, Cx, H, W, OH, OW, stride, M, K, OutH,
+                        OutW, ostride, shift, res, mask, relu, workspace, ws_bytes, stream);
+}
+
+extern "C" int dasac_conv_pack_x3(const float* packed, int M, int K, void* packed_x3, dasac_stream_t stream) {
+  DASAC_REQUIRE(packed && packed_x3, "conv_pack_x3: null pointer");
+  const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
+  hipLaunchKernelGGL(pack_x3, dim3(stream_grid((int64_t)(Kpad / 8) * Mpad, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const f32x4*>(packed), reinterpret_cast<f32x4*>(packed_x3), Mpad, Kpad);
+  DASAC_CHECK_LAUNCH("pack_x3");
   return DASAC_OK;
 }
 

@@ -204,7 +204,7 @@ class Engine:
         return t
 
     def packed_e(self, op, transposed):
-        key = tuple(_ver(c.weight) for c in op.convs)
+        key = tuple(_ver(c.weight) for c in op.convs) + (ops.PRECISION,)
         slot = (id(op), "e", transposed)
         ent = self._packs.get(slot)
         if ent is None or ent[0] != key:
@@ -214,7 +214,7 @@ class Engine:
         return ent[1]
 
     def packed(self, op, transposed, scale=None):
-        key = tuple(_ver(c.weight) for c in op.convs) + ((_ver(scale),) if scale is not None else ())
+        key = tuple(_ver(c.weight) for c in op.convs) + ((_ver(scale),) if scale is not None else ()) + (ops.PRECISION,)
         slot = (id(op), transposed)
         ent = self._packs.get(slot)
         if ent is None or ent[0] != key:

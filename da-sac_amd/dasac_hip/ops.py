@@ -106,6 +106,28 @@ class ConvSpec:
 
 _i32 = torch.int32
 
+# Arithmetic of the forward / data-gradient GEMMs:
+#   "fp32"   exact fp32 products on v_mfma_f32_32x32x2_f32 (default);
+#   "bf16x3" every operand split into bf16 head + tail, three v_mfma_f32_32x32x16_bf16 per product, fp32
+#            accumulation (dasac_conv_gemm_x3; ~2^-16 relative error per product, inside the 1e-3 parity bar).
+PRECISION = os.environ.get("DASAC_PRECISION", "fp32")
+
+
+def set_precision(mode):
+    global PRECISION
+    assert mode in ("fp32", "bf16x3"), mode
+    PRECISION = mode
+
+
+def _finish_pack(packed, M, K):
+    """Converts a freshly packed fp32 operand to the split-bf16 layout (in place, same size) when selected."""
+    lib = L.load()
+    x3 = PRECISION == "bf16x3" and lib.dasac_conv_mpad(M) >= 64
+    if x3:
+        L.check(lib.dasac_conv_pack_x3(packed.data_ptr(), M, K, packed.data_ptr(), L.stream_ptr()), "dasac_conv_pack_x3")
+    packed.dasac_x3 = x3
+    return packed
+
 
 def gemm_order(spec, transposed):
     """K order of the forward / data-gradient GEMM: chunk-major (1) for multi-tap convs whose gathered channel
@@ -141,7 +163,7 @@ def conv_pack(spec, weights, transposed, scale=None, out=None, order=0):
         L.check(lib.dasac_conv_pack(_c(w).data_ptr(), L.ptr(scale), spec.cout, spec.cin, kh * kw, tap0, spec.taps,
                                     int(transposed), int(order), out.data_ptr(), L.stream_ptr()), "dasac_conv_pack")
         tap0 += kh * kw
-    return out
+    return _finish_pack(out, M, K)
 
 
 def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=None, res=None, mask=None, relu=False):
@@ -158,9 +180,10 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     if PROFILE.on:
         span = "conv_gemm<stream-K>" if lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K) else "conv_gemm<tile-per-block>"
     with PROFILE.span(span, 2.0 * Nb * OH * OW * M * K, (M, K, Nb * OH * OW, stride, ostride, res is not None, mask is not None)):
-        L.check(lib.dasac_conv_gemm(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
-                                    stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
-                                    L.ptr(mask), int(relu), L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr()),
+        fn = lib.dasac_conv_gemm_x3 if getattr(packed, "dasac_x3", False) else lib.dasac_conv_gemm
+        L.check(fn(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
+                   stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
+                   L.ptr(mask), int(relu), L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr()),
                 "dasac_conv_gemm")
     return out
 
@@ -563,7 +586,7 @@ class ExpandedConv:
             L.check(lib.dasac_conv_pack_expanded(_c(w).data_ptr(), self.spec.cout, self.spec.cin, kh * kw, tap0, self.spec.taps,
                                                  self.cp, int(transposed), out.data_ptr(), L.stream_ptr()), "dasac_conv_pack_expanded")
             tap0 += kh * kw
-        return out
+        return _finish_pack(out, M, K)
 
     def forward(self, x, packed, table, bias):
         """x [B,Cin,H,W] -> out [B,Cout,H,W]."""

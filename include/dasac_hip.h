@@ -93,6 +93,19 @@ int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, f
                     int OutH, int OutW, int ostride,
                     const float* shift, const float* res, const float* mask,
                     int relu, void* workspace, size_t ws_bytes, dasac_stream_t stream);
+/* Split-bf16 ("bf16x3") variant of the same contraction: every fp32 operand x is split into
+ * head = bf16(x) and tail = bf16(x - head) and x*y is evaluated as xh*yh + xh*yl + xl*yh on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error of a product <= ~2^-15, typically
+ * 2^-17; the dropped tail*tail term is below 2^-16).  The activations are split inside the kernel
+ * (NCHW fp32 in HBM, nothing else changes), the weights once by dasac_conv_pack_x3 from the output of
+ * dasac_conv_pack (same byte size).  Same table, epilogue, workspace and schedule as dasac_conv_gemm;
+ * M must exceed 32.  Opt-in: the host picks it per call (DASAC_PRECISION=bf16x3 in the Python layer). */
+int dasac_conv_pack_x3(const float* packed, int M, int K, void* packed_x3, dasac_stream_t stream);
+int dasac_conv_gemm_x3(const float* x, const void* packed_x3, const int32_t* table, float* out,
+                       int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
+                       int OutH, int OutW, int ostride,
+                       const float* shift, const float* res, const float* mask,
+                       int relu, void* workspace, size_t ws_bytes, dasac_stream_t stream);
 size_t dasac_conv_gemm_workspace(void);
 int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K);   /* 1 = stream-K, 0 = one block per tile */
 size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K);

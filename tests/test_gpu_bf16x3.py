@@ -1,0 +1,125 @@
+"""Opt-in split-bf16 ("bf16x3") arithmetic of the forward / data-gradient GEMMs (dasac_conv_gemm_x3):
+kernel level against the exact-fp32 kernel, network level against the reference goldens and the oracle.
+Tolerance: north_star's 1e-3 rel (of max) for logits / gradients, written per assert (tighter where measured)."""
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import nets_ref as N
+from conftest import rel_err
+from test_gpu_models import CRIT, T, _all_grads, model_cfg, sampled
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16x3():
+    from dasac_hip import ops
+    ops.set_precision("bf16x3")
+    yield ops
+    ops.set_precision("fp32")
+
+
+CASES = [
+    # cin, cout, branches, stride, H, W
+    (64, 64, [(3, 3, 1, 1)], 1, 37, 41),            # FAST, chunk-major K order, 64-row tile
+    (256, 128, [(1, 1, 1, 0)], 2, 33, 35),          # strided 1x1 (scatter data gradient)
+    (3, 64, [(7, 7, 1, 3)], 2, 65, 67),             # table-driven gather (stem), K = 147 padded to 160
+    (128, 80, [(3, 3, 2, 2)], 1, 29, 31),           # M = 80 of a 128-row tile
+    (64, 76, [(1, 1, 1, 0)], 1, 23, 27),            # ragged M (not a multiple of 8)
+    (512, 256, [(3, 3, 4, 4)], 1, 97, 97),          # B=8: 1178 tiles x 288 K-steps -> persistent stream-K schedule
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16x3_matches_fp32_kernel(case, bf16x3):
+    ops = bf16x3
+    cin, cout, br, stride, H, W = case
+    B = 8 if cin == 512 else 2
+    spec = ops.ConvSpec(cin, cout, br, stride)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g).cuda()
+    ws = [(torch.randn(cout, cin, b[0], b[1], generator=g) * (2.0 / (cin * b[0] * b[1])) ** 0.5).cuda() for b in br]
+    OH, OW = spec.out_hw(H, W)
+    dz = torch.randn(B, cout, OH, OW, generator=g).cuda()
+    shift = torch.randn(cout, generator=g).cuda()
+    res = torch.randn(B, cout, OH, OW, generator=g).cuda()
+    mask = torch.randn(B, cin, H, W, generator=g).cuda()
+    out = {}
+    for mode in ("fp32", "bf16x3"):
+        ops.set_precision(mode)
+        y = ops.conv_forward(spec, x, ws, shift=shift, res=res, relu=True)
+        pk = ops.conv_pack(spec, ws, False)
+        assert bool(pk.dasac_x3) == (mode == "bf16x3")
+        dx = ops.conv_dgrad(spec, dz, ws, (H, W), mask=mask) if cin >= 64 else None
+        out[mode] = (y, dx)
+    assert rel_err(out["bf16x3"][0], out["fp32"][0]) < 3e-5
+    if out["fp32"][1] is not None:
+        assert rel_err(out["bf16x3"][1], out["fp32"][1]) < 3e-5
+    # and against ATen in float64 (forward)
+    ref = sum(nn.functional.conv2d(x.double().cpu(), w.double().cpu(), stride=stride, padding=b[3], dilation=b[2])
+              for w, b in zip(ws, br))
+    ref = torch.relu(ref + shift.double().cpu().view(1, -1, 1, 1) + res.double().cpu())
+    assert rel_err(out["bf16x3"][0].double().cpu(), ref) < 3e-5
+
+
+def test_skinny_outputs_stay_on_the_fp32_kernel(bf16x3):
+    ops = bf16x3
+    spec = ops.ConvSpec(64, 19, [(1, 1, 1, 0)], 1)
+    w = torch.randn(19, 64, 1, 1, device="cuda")
+    assert not ops.conv_pack(spec, [w], False).dasac_x3          # M <= 32: 32x256 tile, exact path
+    x = torch.randn(1, 64, 9, 11, device="cuda")
+    y = ops.conv_forward(spec, x, [w])
+    assert rel_err(y, nn.functional.conv2d(x, w)) < 1e-5
+
+
+def test_resnet101_golden_g2_bf16x3(golden, bf16x3):
+    import models
+    g = golden("g2_resnet101")
+    net = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=True)
+    net.load_state_dict(N.resnet101_state(seed=2, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
+    net.cuda().train()
+    losses, outs = net(T(g["eval_x"]).cuda(), T(g["eval_y"]).cuda())
+    losses["loss_ce"].mean().backward()
+    assert rel_err(outs["logits"], g["eval_logits"]) < 1e-3           # north_star tolerance (measured ~1e-4)
+    assert rel_err(sampled(outs["logits_up"], 512), g["eval_logits_up_s"]) < 1e-3
+    assert rel_err(losses["loss_ce"], g["eval_loss"]) < 1e-4
+    named = dict(net.named_parameters())
+    for k in [k[len("eval_g_"):] for k in g.files if k.startswith("eval_g_")]:
+        gn = float(g["eval_gn_" + k])
+        # raw (ReLU pattern not shared): a 1e-5 perturbation flips a few more borderline units than fp32 does, see
+        # test_gpu_models.test_resnet101_gradients_with_borderline_relu; the shared-pattern test below is the tight one
+        assert abs(float(named[k].grad.norm()) - gn) < 5e-3 * gn, k
+
+
+def test_resnet101_all_gradients_bf16x3(bf16x3):
+    """All 320 parameter gradients against oracle autograd with the ReLU pattern shared (see
+    test_gpu_models._all_grads): the split-bf16 products keep every gradient within 1e-4 of its max."""
+    errs, act = _all_grads(1, share_masks=True)
+    assert len(errs) == 320
+    assert act.disagree <= 1e-4 * act.total, (act.disagree, act.total)
+    assert errs[0][0] < 1e-4, errs[:3]
+
+
+def test_two_sac_steps_golden_g8_bf16x3(golden, bf16x3):
+    import models
+    import driver
+    g = golden("g8_two_steps")
+    cfg = model_cfg()
+    net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT)
+    net.backbone.load_state_dict(N.resnet101_state(seed=8, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
+    net.cuda().train()
+    optim = driver.make_optimizer(net, cfg)
+    aff, inv = T(g["affine"]).cuda(), T(g["affine_inv"]).cuda()
+    for it in range(2):
+        src = (T(g["it%d_xs" % it]).cuda(), T(g["it%d_ys" % it]).cuda())
+        tgt = (T(g["it%d_f1" % it]).cuda(), T(g["it%d_gt" % it]).cuda(), T(g["it%d_f2" % it]).cuda(), aff, inv)
+        ls, lt, outs = driver.sac_train_iteration(net, optim, src, tgt, int(g["T"]), it % 100 == 0, cfg.LR_TARGET)
+        assert float(ls["loss_ce"]) == pytest.approx(float(g["it%d_src_loss" % it].item()), rel=1e-3)
+        for k in ("loss_ce", "self_ce", "teacher_diff"):
+            assert float(lt[k]) == pytest.approx(float(g["it%d_%s" % (it, k)].item()), rel=3e-3, abs=1e-6), (it, k)
+        mism = (outs["teacher_labels"].to(torch.uint8).cpu() != T(g["it%d_labels" % it])).float().mean()
+        assert mism < 2e-3, (it, float(mism))
+        st = net.backbone.state_dict()
+        for k in [k[len("it0_p_"):] for k in g.files if k.startswith("it0_p_")]:
+            assert rel_err(sampled(st[k]), g["it%d_p_%s" % (it, k)]) < 1e-3, (it, k)
