@@ -439,7 +439,12 @@ constexpr int kWgPitch = 33;
 // FAST: Cx % BN == 0 (the 128 im2col rows of a block belong to ONE tap) and M % 8 == 0: one (dh, dw)
 // per block, the per-row part of both operand addresses is a scalar offset, the pixel position is
 // advanced incrementally (no divisions in the loop) -> ~25 VALU per 64 MFMAs.
-template <int BM, int BN, int WAVES_M, bool FAST>
+// X3: split-bf16 arithmetic (see conv_gemm).  The loader is unchanged (lane = pixel); every element is split
+// into bf16 head + tail on its way to LDS (three VALU each: v_cvt_pk_bf16_f32 with the value in the HIGH half
+// gives the head as an fp32 bit pattern directly) and stored with 16-bit writes into [octet of 8 pixels][row][8]
+// operand words; the octet pitch rows+2 keeps the 64 lanes of a store on distinct banks and the 16-byte MFMA
+// operand reads of consecutive rows contiguous.
+template <int BM, int BN, int WAVES_M, bool FAST, bool X3>
 __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
                                                        float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
@@ -451,8 +456,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
 
   // ONE LDS stage (34 KB for the 128x128 tile -> 4 blocks per CU); the next tile waits in registers while the
   // MFMAs run, two barriers per step.  More co-resident blocks hide the extra barrier (measured).
-  __shared__ float sA[1][BM * kWgPitch];
-  __shared__ float sB[1][BN * kWgPitch];
+  constexpr int PA = BM + 2, PB = BN + 2;                // X3: operand words per pixel octet (rows + 2)
+  __shared__ __attribute__((aligned(16))) float sA[1][X3 ? 32 * PA : BM * kWgPitch];   // X3: [head|tail][4 octets][PA] x 16 B
+  __shared__ __attribute__((aligned(16))) float sB[1][X3 ? 32 * PB : BN * kWgPitch];
 
   const int tile = blockIdx.x % (m_tiles * k_tiles), split = blockIdx.x / (m_tiles * k_tiles);
   const int m_tile = tile % m_tiles, k_tile = tile / m_tiles;
@@ -536,7 +542,24 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     while (poh >= g.OH) { poh -= g.OH; ++pn; }                                                       \
   }
 #define DASAC_WG_STORE(buf)                                                                          \
-  {                                                                                                  \
+  if (X3) {                                                                                          \
+    unsigned short* a16 = reinterpret_cast<unsigned short*>(&sA[buf][0]);                            \
+    unsigned short* b16 = reinterpret_cast<unsigned short*>(&sB[buf][0]);                            \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                            \
+      const unsigned h = pack_bf16(0.f, ra[i]);                                                      \
+      const unsigned l = pack_bf16(0.f, ra[i] - __uint_as_float(h));                                 \
+      const int e = (((pl >> 3) * PA + prow + i * 8) << 3) + (pl & 7);                               \
+      a16[e] = (unsigned short)(h >> 16);                                                            \
+      a16[32 * PA + e] = (unsigned short)(l >> 16);                                                  \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                            \
+      const unsigned h = pack_bf16(0.f, rb[i]);                                                      \
+      const unsigned l = pack_bf16(0.f, rb[i] - __uint_as_float(h));                                 \
+      const int e = (((pl >> 3) * PB + prow + i * 8) << 3) + (pl & 7);                               \
+      b16[e] = (unsigned short)(h >> 16);                                                            \
+      b16[32 * PB + e] = (unsigned short)(l >> 16);                                                  \
+    }                                                                                                \
+  } else {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) sA[buf][(prow + i * 8) * kWgPitch + pl] = ra[i]; \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) sB[buf][(prow + i * 8) * kWgPitch + pl] = rb[i]; \
   }
@@ -556,6 +579,33 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     if (s + 1 < steps) DASAC_WG_LOAD();
+    if (X3) {
+      const f32x4* a4 = reinterpret_cast<const f32x4*>(&sA[0][0]) + wm * WM + li;
+      const f32x4* b4 = reinterpret_cast<const f32x4*>(&sB[0][0]) + wn * WN + li;
+#pragma unroll
+      for (int kb = 0; kb < kWgPix / 16; ++kb) {
+        const int oct = 2 * kb + lh;                     // this lane half's 8 pixels of the 16-pixel MFMA block
+        f32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = a4[oct * PA + i * 32];
+          al[i] = a4[(4 + oct) * PA + i * 32];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = b4[oct * PB + j * 32];
+          bl[j] = b4[(4 + oct) * PB + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(al[i]), as_bf16x8(bh[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ah[i]), as_bf16x8(bl[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ah[i]), as_bf16x8(bh[j]), acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
     const float* a_base = &sA[0][(wm * WM + li) * kWgPitch + lh];
     const float* b_base = &sB[0][(wn * WN + li) * kWgPitch + lh];
 #pragma unroll
@@ -569,6 +619,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
     }
     __syncthreads();
     if (s + 1 < steps) {
@@ -791,11 +842,15 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
 }
 
 template <int BM, int BN, int WAVES_M, bool FAST>
-static void launch_wgrad(const float* dZ, const float* X, const int4* tab, float* P, float* Psum, const GemmGeom& g,
+static void launch_wgrad(bool x3, const float* dZ, const float* X, const int4* tab, float* P, float* Psum, const GemmGeom& g,
                          int splits, int pix_per_split, hipStream_t s) {
   const int m_tiles = g.Mpad / BM, k_tiles = g.Kpad / BN;
-  hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P, Psum,
-                     g, m_tiles, k_tiles, pix_per_split);
+  if (x3)
+    hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST, true>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P,
+                       Psum, g, m_tiles, k_tiles, pix_per_split);
+  else
+    hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST, false>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P,
+                       Psum, g, m_tiles, k_tiles, pix_per_split);
 }
 
 }  // namespace dasac
@@ -961,8 +1016,8 @@ extern "C" size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int 
 }
 
 // dz [Nb,M,OH,OW], x [Nb,Cx,H,W] -> slabs in workspace -> dW (one or several weight tensors of a fused conv)
-extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table, int Nb, int Cx, int H, int W, int OH,
-                                int OW, int stride, int M, int K, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+static int conv_wgrad_impl(bool x3, const float* dz, const float* x, const int32_t* table, int Nb, int Cx, int H, int W, int OH,
+                           int OW, int stride, int M, int K, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
   DASAC_REQUIRE(dz && x && table && workspace, "conv_wgrad: null pointer");
   GemmGeom g;
   const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
@@ -980,24 +1035,34 @@ extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* 
   hipStream_t s = as_stream(stream);
   const bool fast = (Cx % 128 == 0) && (M % 8 == 0);   // a 128-row k tile sits inside one tap
   if (bnk == 64) {                                     // Cx = 64, 192, ...: 64-row k tiles, still one tap each
-    if (bm == 128) launch_wgrad<128, 64, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
-    else launch_wgrad<64, 64, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
+    if (bm == 128) launch_wgrad<128, 64, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
+    else launch_wgrad<64, 64, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
     DASAC_CHECK_LAUNCH("conv_wgrad");
     return DASAC_OK;
   }
   switch (bm) {
     case 128:
-      if (fast) launch_wgrad<128, 128, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
-      else launch_wgrad<128, 128, 2, false>(dz, x, tab, P, Psum, g, splits, per, s);
+      if (fast) launch_wgrad<128, 128, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
+      else launch_wgrad<128, 128, 2, false>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       break;
     case 64:
-      if (fast) launch_wgrad<64, 128, 2, true>(dz, x, tab, P, Psum, g, splits, per, s);
-      else launch_wgrad<64, 128, 2, false>(dz, x, tab, P, Psum, g, splits, per, s);
+      if (fast) launch_wgrad<64, 128, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
+      else launch_wgrad<64, 128, 2, false>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       break;
-    default: launch_wgrad<32, 128, 1, false>(dz, x, tab, P, Psum, g, splits, per, s); break;
+    default: launch_wgrad<32, 128, 1, false>(x3, dz, x, tab, P, Psum, g, splits, per, s); break;
   }
   DASAC_CHECK_LAUNCH("conv_wgrad");
   return DASAC_OK;
+}
+
+extern "C" int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table, int Nb, int Cx, int H, int W, int OH,
+                                int OW, int stride, int M, int K, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  return conv_wgrad_impl(false, dz, x, table, Nb, Cx, H, W, OH, OW, stride, M, K, workspace, ws_bytes, stream);
+}
+
+extern "C" int dasac_conv_wgrad_x3(const float* dz, const float* x, const int32_t* table, int Nb, int Cx, int H, int W, int OH,
+                                   int OW, int stride, int M, int K, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  return conv_wgrad_impl(true, dz, x, table, Nb, Cx, H, W, OH, OW, stride, M, K, workspace, ws_bytes, stream);
 }
 
 extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K, const float* w,

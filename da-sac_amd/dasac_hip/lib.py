@@ -27,6 +27,7 @@ PROTOTYPES = {
     "dasac_conv_gemm_schedule": (_i, [_i, _i, _i, _i, _i]),
     "dasac_conv_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dasac_conv_wgrad": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
+    "dasac_conv_wgrad_x3": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
     "dasac_upsample_softmax": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dasac_upsample_bwd_workspace": (_sz, [_i, _i, _i]),
     "dasac_upsample_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),

@@ -233,8 +233,9 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=No
     nbytes = lib.dasac_conv_wgrad_workspace(Nb, OH, OW, M, spec.K)
     ws = L.workspace(nbytes, x.device)
     with PROFILE.span("conv_wgrad", 2.0 * Nb * OH * OW * M * spec.K, (M, spec.K, Nb * OH * OW, spec.stride, 1, False, False)):
-        L.check(lib.dasac_conv_wgrad(_c(dz).data_ptr(), x.data_ptr(), table.data_ptr(), Nb, Cx, H, W, OH, OW, spec.stride, M,
-                                     spec.K, ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
+        fn = lib.dasac_conv_wgrad_x3 if PRECISION == "bf16x3" else lib.dasac_conv_wgrad
+        L.check(fn(_c(dz).data_ptr(), x.data_ptr(), table.data_ptr(), Nb, Cx, H, W, OH, OW, spec.stride, M,
+                   spec.K, ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
     grads, tap0 = [], 0
     for w, (kh, kw, _, _) in zip(weights, spec.branches):
         dw = torch.empty_like(w)
@@ -614,8 +615,9 @@ class ExpandedConv:
         nbytes = lib.dasac_conv_wgrad_workspace(B, H, W, self.E, self.spec.cin)
         ws = L.workspace(nbytes, x.device)
         with PROFILE.span("conv_wgrad", 2.0 * B * H * W * self.E * self.spec.cin, (self.E, self.spec.cin, B * H * W, 1, 1, False, False)):
-            L.check(lib.dasac_conv_wgrad(d.data_ptr(), x.data_ptr(), table.data_ptr(), B, Cx, H, W, H, W, 1, self.E, self.spec.cin,
-                                         ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
+            fn = lib.dasac_conv_wgrad_x3 if PRECISION == "bf16x3" else lib.dasac_conv_wgrad
+            L.check(fn(d.data_ptr(), x.data_ptr(), table.data_ptr(), B, Cx, H, W, H, W, 1, self.E, self.spec.cin,
+                       ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
         grads, tap0 = [], 0
         for w, (kh, kw, _, _) in zip(weights, self.spec.branches):
             dw = torch.empty_like(w)

@@ -112,6 +112,11 @@ size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K);
 int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
                      int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                      void* workspace, size_t ws_bytes, dasac_stream_t stream);
+/* split-bf16 variant of dasac_conv_wgrad (same arguments, workspace layout and dasac_conv_wgrad_finish):
+ * both operands are split on their way into LDS, three bf16 MFMAs per product, fp32 accumulate. */
+int dasac_conv_wgrad_x3(const float* dz, const float* x, const int32_t* table,
+                        int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
+                        void* workspace, size_t ws_bytes, dasac_stream_t stream);
 int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K,
                             const float* w, const float* scale, float* dw, float* dot,
                             float* sum_dz, int Cin, int taps, int tap0, dasac_stream_t stream);

@@ -52,10 +52,15 @@ def test_conv_bf16x3_matches_fp32_kernel(case, bf16x3):
         pk = ops.conv_pack(spec, ws, False)
         assert bool(pk.dasac_x3) == (mode == "bf16x3")
         dx = ops.conv_dgrad(spec, dz, ws, (H, W), mask=mask) if cin >= 64 else None
-        out[mode] = (y, dx)
+        sums = torch.zeros(cout, device="cuda")
+        dws = ops.conv_wgrad(spec, dz, x, ws, sum_dz=sums)
+        out[mode] = (y, dx, dws, sums)
     assert rel_err(out["bf16x3"][0], out["fp32"][0]) < 3e-5
     if out["fp32"][1] is not None:
         assert rel_err(out["bf16x3"][1], out["fp32"][1]) < 3e-5
+    for a, b in zip(out["bf16x3"][2], out["fp32"][2]):
+        assert rel_err(a, b) < 3e-5
+    assert torch.equal(out["bf16x3"][3], out["fp32"][3])            # channel sums of dz stay exact fp32 adds
     # and against ATen in float64 (forward)
     ref = sum(nn.functional.conv2d(x.double().cpu(), w.double().cpu(), stride=stride, padding=b[3], dilation=b[2])
               for w, b in zip(ws, br))

@@ -53,6 +53,12 @@ def run(mode, spec, x, ws, dz, H, W, OH, OW, shift, res, mask):
         g = lambda: ops.conv_dgrad(spec, dz, ws, (H, W), table=tabt, packed=pkt, mask=mask)
         td = timeit(g)
         out += [g().clone(), td]
+    else:
+        out += [None, 0.0]
+    tabw = ops.conv_table(spec, H, W, False, x.device, 0)
+    h = lambda: ops.conv_wgrad(spec, dz, x, ws, table=tabw)
+    tw = timeit(h)
+    out += [h()[0].clone(), tw]
     return out
 
 
@@ -72,9 +78,11 @@ for name, cin, cout, br, stride, H, W in SHAPES:
     e_f = float((a[0] - b[0]).abs().max() / a[0].abs().max())
     line = "{:18s} fwd fp32 {:6.1f} TF  x3 {:6.1f} TF-eq ({:4.2f}x)  err {:.1e}".format(
         name, flops / a[1] / 1e12, flops / b[1] / 1e12, a[1] / b[1], e_f)
-    if len(a) > 2:
+    if a[2] is not None:
         e_d = float((a[2] - b[2]).abs().max() / a[2].abs().max())
         line += " | dgrad fp32 {:6.1f}  x3 {:6.1f} ({:4.2f}x) err {:.1e}".format(flops / a[3] / 1e12, flops / b[3] / 1e12, a[3] / b[3], e_d)
+    e_w = float((a[4] - b[4]).abs().max() / a[4].abs().max())
+    line += " | wgrad fp32 {:6.1f}  x3 {:6.1f} ({:4.2f}x) err {:.1e}".format(flops / a[5] / 1e12, flops / b[5] / 1e12, a[5] / b[5], e_w)
     print(line, flush=True)
 
 # against float64 on a small case
