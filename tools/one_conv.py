@@ -15,7 +15,8 @@ x = torch.randn(B, cin, H, W, device="cuda")
 ws = [torch.randn(cout, cin, b[0], b[1], device="cuda") * 0.05 for b in br]
 OH, OW = spec.out_hw(H, W)
 dz = torch.randn(B, cout, OH, OW, device="cuda")
-tab = ops.conv_table(spec, H, W, False, x.device); pk = ops.conv_pack(spec, ws, False)
+order = ops.gemm_order(spec, False) if mode == "fwd" else 0      # DASAC_PRECISION=bf16x3 selects the split-bf16 kernels
+tab = ops.conv_table(spec, H, W, False, x.device, order); pk = ops.conv_pack(spec, ws, False, order=order)
 y = torch.empty(B, cout, OH, OW, device="cuda")
 for _ in range(iters):
     if mode == "fwd":
