@@ -106,6 +106,57 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
   }
 }
 
+// ---- inference (infer_val.py:160-163 + the writer's argmax / trainId->labelId LUT, :60-65): bilinear(ac=True) +
+// softmax + argmax + LUT in one pass over the low-resolution logits; writes 1 byte (+ optional confidence) per
+// high-resolution pixel instead of two [C,H,W] fp32 tensors.  Same per-pixel arithmetic as upsample_softmax.
+template <int CT>
+__global__ __launch_bounds__(kHB) void infer_labels(const float* __restrict__ x, int Crt, int h, int w, int H, int W, float sh,
+                                                    float sw, const uint8_t* __restrict__ lut, uint8_t* __restrict__ labels,
+                                                    float* __restrict__ conf, int blocks_per_image) {
+  const int C = CT < kMaxC ? CT : Crt;
+  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
+  const int HW = H * W, hw = h * w;
+  const float* xb = x + (size_t)b * C * hw;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const int oy = p / W, ox = p - oy * W;
+    const Tap ty = tap_ac(oy, sh, h), tx = tap_ac(ox, sw, w);
+    const int o00 = ty.i0 * w + tx.i0, o01 = ty.i0 * w + tx.i1, o10 = ty.i1 * w + tx.i0, o11 = ty.i1 * w + tx.i1;
+    float v[CT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      if (c < C) {
+        const float* pl = xb + (size_t)c * hw;
+        const float top = tx.w0 * pl[o00] + tx.w1 * pl[o01];
+        const float bot = tx.w0 * pl[o10] + tx.w1 * pl[o11];
+        v[c] = ty.w0 * top + ty.w1 * bot;
+        mx = fmaxf(mx, v[c]);
+      }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+        v[c] = expf(v[c] - mx);
+        den += v[c];
+      }
+    const float inv = 1.f / den;
+    int best = 0;
+    float bp = -1.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+        const float pr = v[c] * inv;
+        if (pr > bp) {             // strict: the first maximum wins, as torch.argmax / numpy.argmax
+          bp = pr;
+          best = c;
+        }
+      }
+    labels[(size_t)b * HW + p] = lut ? lut[best] : (uint8_t)best;
+    if (conf) conf[(size_t)b * HW + p] = bp;
+  }
+}
+
 // ---- transpose of the bilinear upsampling, separable and gather-based (deterministic) ---------
 // pass X: tmp[plane][y][j] = sum_x wx(x->j) * g[plane][y][x]          (reads the big gradient once)
 // pass Y: d[plane][i][j]   = gscale * sum_y wy(y->i) * tmp[plane][y][j]
@@ -431,6 +482,22 @@ extern "C" int dasac_upsample_softmax(const float* logits, int B, int C, int h, 
     hipLaunchKernelGGL(upsample_softmax<kMaxC>, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H),
                        ac_scale(w, W), ignore, up, probs, class_sums, per);
   DASAC_CHECK_LAUNCH("upsample_softmax");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_infer_labels(const float* logits, int B, int C, int h, int w, int H, int W, const uint8_t* lut,
+                                  uint8_t* labels, float* conf, dasac_stream_t stream) {
+  DASAC_REQUIRE(logits && labels, "infer_labels: null pointer");
+  DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && h > 0 && w > 0 && H > 0 && W > 0, "infer_labels: bad shape");
+  const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
+  hipStream_t s = as_stream(stream);
+  if (C == 19)
+    hipLaunchKernelGGL(infer_labels<19>, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), ac_scale(w, W), lut,
+                       labels, conf, per);
+  else
+    hipLaunchKernelGGL(infer_labels<kMaxC>, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), ac_scale(w, W), lut,
+                       labels, conf, per);
+  DASAC_CHECK_LAUNCH("infer_labels");
   return DASAC_OK;
 }
 

@@ -155,6 +155,44 @@ __global__ void ema_finish(const double* __restrict__ sq, int n, float* __restri
   if (threadIdx.x == 0) out[0] = (float)s;
 }
 
+// ---- torch.optim.SGD(momentum, dampening 0, no nesterov) over every parameter in one launch ---------
+// (base_trainer.py:63-66 builds it over the four groups of basenet.py:73-95; per-group lr / weight decay)
+//   d = g + wd*p ;  buf = first ? d : momentum*buf + d ;  p = p - lr*buf        (same op order as ATen)
+struct SgdTensor {
+  float* p;
+  const float* g;
+  float* buf;
+  int64_t n;
+  int64_t group;
+};
+struct SgdGroups {
+  float lr[8], wd[8];
+};
+
+__global__ __launch_bounds__(256) void sgd_chunks(const SgdTensor* __restrict__ tensors, const int2* __restrict__ chunks,
+                                                  SgdGroups hp, float momentum, int first) {
+  const int2 ch = chunks[blockIdx.x];
+  const SgdTensor t = tensors[ch.x];
+  const float lr = hp.lr[t.group], wd = hp.wd[t.group];
+  const int64_t base = (int64_t)ch.y * kEmaChunk;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i < t.n) {
+      const float p = t.p[i];
+      float d = t.g[i];
+      if (wd != 0.f) d = d + wd * p;
+      float b = d;
+      if (!first) {
+        b = t.buf[i] * momentum;
+        b = b + d;
+      }
+      t.buf[i] = b;
+      t.p[i] = p - lr * b;
+    }
+  }
+}
+
 // y[n,c,:] = x[n,c,:] * m[n,c]   (Dropout2d with an explicit keep/(1-p) mask, fcn.py:52,56)
 __global__ __launch_bounds__(256) void scale_planes(const float* __restrict__ x, const float* __restrict__ m, int HW,
                                                     float* __restrict__ y, int64_t total) {
@@ -240,6 +278,21 @@ extern "C" int dasac_ema_update(const void* pairs, int n_tensors, const int32_t*
   DASAC_CHECK_LAUNCH("ema_chunks");
   hipLaunchKernelGGL(ema_finish, dim3(1), dim3(64), 0, s, sq, n_tensors, out);
   DASAC_CHECK_LAUNCH("ema_finish");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_sgd_step(const void* tensors, int n_tensors, const int32_t* chunks, int n_chunks, const float* group_lr,
+                              const float* group_wd, int n_groups, float momentum, int first, dasac_stream_t stream) {
+  DASAC_REQUIRE(tensors && chunks && group_lr && group_wd && n_tensors > 0 && n_chunks > 0, "sgd_step: bad arguments");
+  DASAC_REQUIRE(n_groups >= 1 && n_groups <= 8, "sgd_step: 1..8 parameter groups");
+  SgdGroups hp;
+  for (int i = 0; i < 8; ++i) {
+    hp.lr[i] = i < n_groups ? group_lr[i] : 0.f;
+    hp.wd[i] = i < n_groups ? group_wd[i] : 0.f;
+  }
+  hipLaunchKernelGGL(sgd_chunks, dim3(n_chunks), dim3(256), 0, as_stream(stream), reinterpret_cast<const SgdTensor*>(tensors),
+                     reinterpret_cast<const int2*>(chunks), hp, momentum, first);
+  DASAC_CHECK_LAUNCH("sgd_chunks");
   return DASAC_OK;
 }
 

@@ -29,6 +29,7 @@ PROTOTYPES = {
     "dasac_conv_wgrad": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
     "dasac_conv_wgrad_x3": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
     "dasac_upsample_softmax": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "dasac_infer_labels": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dasac_upsample_bwd_workspace": (_sz, [_i, _i, _i]),
     "dasac_upsample_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "dasac_ce_loss_workspace": (_sz, [_i, _i, _l]),
@@ -44,6 +45,7 @@ PROTOTYPES = {
     "dasac_maxpool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_ema_chunk_elems": (_i, []),
     "dasac_ema_update": (_i, [_p, _i, _p, _i, _f, _i, _p, _p, _p]),
+    "dasac_sgd_step": (_i, [_p, _i, _p, _i, _p, _p, _i, _f, _i, _p]),
     "dasac_scale_planes": (_i, [_p, _p, _l, _l, _p, _p]),
     "dasac_add": (_i, [_p, _p, _p, _l, _p]),
     "dasac_relu_mask": (_i, [_p, _p, _p, _l, _p]),

@@ -271,6 +271,22 @@ def upsample_softmax(logits, size, ignore=None, want_up=True, want_probs=False, 
     return up, probs, sums
 
 
+def infer_labels(logits, size, lut=None, want_conf=False):
+    """infer_val.py:160-163 + writer: uint8 label map [B,H,W] = lut[argmax softmax(bilinear_ac(logits))] (+ winning prob)."""
+    lib = L.load()
+    L.require_gpu(logits, lut)
+    logits = _c(logits)
+    B, Cn, h, w = logits.shape
+    H, W = int(size[0]), int(size[1])
+    labels = torch.empty((B, H, W), dtype=torch.uint8, device=logits.device)
+    conf = _f32((B, H, W), logits) if want_conf else None
+    if lut is not None:
+        assert lut.dtype == torch.uint8 and lut.numel() >= Cn and lut.is_contiguous()
+    L.check(lib.dasac_infer_labels(logits.data_ptr(), B, Cn, h, w, H, W, L.ptr(lut), labels.data_ptr(), L.ptr(conf),
+                                   L.stream_ptr()), "dasac_infer_labels")
+    return labels, conf
+
+
 def upsample_bwd(grad_up, low_hw, gscale=None):
     lib = L.load()
     L.require_gpu(grad_up, gscale)
@@ -454,6 +470,13 @@ def scale_planes(x, plane_scale):
     return out
 
 
+def bump_versions(tensors):
+    """Kernels write parameters through raw pointers; autograd's version counters (which key the engine's packed-weight
+    and BN-fold caches) have to be told."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
+
+
 class EmaPlan:
     """Device-side pointer/chunk tables for the multi-tensor teacher update (built once; rebuilt by the
     caller when parameter storage moves)."""
@@ -476,6 +499,7 @@ class EmaPlan:
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
         self.sq = torch.empty(len(fast_tensors), dtype=torch.float64, device=dev)
         self.n_tensors, self.n_chunks = len(fast_tensors), len(chunks)
+        self.slow = list(slow_tensors)
 
     def run(self, momentum, update):
         lib = L.load()
@@ -483,6 +507,8 @@ class EmaPlan:
         L.check(lib.dasac_ema_update(self.pairs.data_ptr(), self.n_tensors, self.chunks.data_ptr(), self.n_chunks,
                                      float(momentum), int(bool(update)), self.sq.data_ptr(), out.data_ptr(), L.stream_ptr()),
                 "dasac_ema_update")
+        if update:
+            bump_versions(self.slow)
         return out
 
 

@@ -1,0 +1,75 @@
+"""Fused multi-tensor SGD for the reference's optimiser (base_trainer.py:63-66:
+`torch.optim.SGD(param_groups, momentum=MOMENTUM, nesterov=OPT_NESTEROV)` over the four groups of
+models/basenet.py:73-95).  Same update rule, `param_groups` and `state[p]["momentum_buffer"]` layout as
+torch.optim.SGD (so LR schedules that poke `param_groups[i]["lr"]` and optimiser checkpoints keep working), but one
+HIP launch (dasac_sgd_step) instead of ~4 foreach passes per group."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False, dampening=0.0):
+        if nesterov or dampening != 0.0:
+            raise NotImplementedError("FusedSGD: plain momentum only (the reference's default OPT_NESTEROV=False)")
+        defaults = dict(lr=lr, momentum=momentum, dampening=0.0, weight_decay=weight_decay, nesterov=False)
+        super().__init__(params, defaults)
+        if len(self.param_groups) > 8:
+            raise ValueError("FusedSGD: at most 8 parameter groups")
+        self._tables = {}            # first(bool) -> (pointer key, device tensor table, device chunk table, n_tensors, n_chunks)
+
+    def _table(self, first, rows, device):
+        key = tuple(v for r in rows for v in r)
+        ent = self._tables.get(first)
+        if ent is None or ent[0] != key:
+            chunk = L.load().dasac_ema_chunk_elems()
+            chunks = [(i, j) for i, r in enumerate(rows) for j in range((r[3] + chunk - 1) // chunk)]
+            ent = (key, torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(device),
+                   torch.tensor(chunks, dtype=torch.int32).to(device), len(rows), len(chunks))
+            self._tables[first] = ent
+        return ent
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.load()
+        momentum = self.param_groups[0]["momentum"]
+        rows = {True: [], False: []}
+        device, keep, touched = None, [], []
+        for gi, group in enumerate(self.param_groups):
+            if group["momentum"] != momentum or group.get("nesterov") or group.get("dampening", 0.0) != 0.0 or group.get("maximize"):
+                raise NotImplementedError("FusedSGD: one momentum for all groups, no nesterov / dampening / maximize")
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                L.require_gpu(p, p.grad)
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
+                    raise TypeError("FusedSGD: dense contiguous fp32 parameters only")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                first = st.get("momentum_buffer") is None
+                if first:
+                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                device = p.device
+                rows[first or momentum == 0.0].append((p.data_ptr(), g.data_ptr(), st["momentum_buffer"].data_ptr(), p.numel(), gi))
+                keep.append(g)                           # a made-contiguous copy must outlive the queued launch
+                touched += [p, st["momentum_buffer"]]
+        n = len(self.param_groups)
+        lr = (ctypes.c_float * n)(*[float(g["lr"]) for g in self.param_groups])
+        wd = (ctypes.c_float * n)(*[float(g["weight_decay"]) for g in self.param_groups])
+        for first in (True, False):
+            if not rows[first]:
+                continue
+            _, tab, chunks, nt, nc = self._table(first, rows[first], device)
+            L.check(lib.dasac_sgd_step(tab.data_ptr(), nt, chunks.data_ptr(), nc, ctypes.cast(lr, ctypes.c_void_p),
+                                       ctypes.cast(wd, ctypes.c_void_p), n, float(momentum), int(first), L.stream_ptr()),
+                    "dasac_sgd_step")
+        ops.bump_versions(touched)       # raw-pointer writes: keep autograd's version counters (engine cache keys) honest
+        return loss

@@ -5,11 +5,16 @@ DistributedDataParallel wrapper (backend "nccl" == RCCL on ROCm)."""
 import torch
 
 
-def make_optimizer(net, cfg_model):
-    """SGD(momentum, no nesterov) over the model's four parameter groups (base_trainer.py:63-66)."""
+def make_optimizer(net, cfg_model, fused=True):
+    """SGD(momentum, no nesterov) over the model's four parameter groups (base_trainer.py:63-66): the fused
+    multi-tensor HIP optimiser (same update rule / state layout) or, with fused=False, torch.optim.SGD itself."""
     core = net.module if hasattr(net, "module") else net
     groups = core.parameter_groups(cfg_model.LR, cfg_model.WEIGHT_DECAY)
-    return torch.optim.SGD(groups, momentum=cfg_model.MOMENTUM, nesterov=getattr(cfg_model, "OPT_NESTEROV", False))
+    nesterov = getattr(cfg_model, "OPT_NESTEROV", False)
+    if fused and not nesterov:
+        from dasac_hip.optim import FusedSGD
+        return FusedSGD(groups, momentum=cfg_model.MOMENTUM)
+    return torch.optim.SGD(groups, momentum=cfg_model.MOMENTUM, nesterov=nesterov)
 
 
 def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_teacher, lr_target, target_only=False):
@@ -186,6 +191,26 @@ def load_checkpoint(path, net, optim=None, map_location="cpu"):
     if optim is not None and blob.get("opt") is not None:
         optim.load_state_dict(blob["opt"])
     return blob.get("epoch", 0), blob.get("score", 0.0), missing, unexpected
+
+
+# Cityscapes train id -> label id (cityscapesScripts `labels`; what infer_val.py:60-65 `convert_to_cs` applies)
+CITYSCAPES_TRAIN_TO_ID = (7, 8, 11, 12, 13, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33)
+
+
+def infer_label_maps(net, image, lut=None, teacher=False, want_conf=False):
+    """infer_val.py:160-163 + the writer's argmax / id mapping, without materialising logits_up or the softmax:
+    backbone -> low-resolution logits -> ONE kernel -> uint8 label map [B,H,W] on the device (PNG writing stays on
+    the host).  `lut`: uint8 tensor / sequence (e.g. CITYSCAPES_TRAIN_TO_ID) or None for train ids."""
+    from dasac_hip import ops
+    core = net.module if hasattr(net, "module") else net
+    backbone = core
+    if hasattr(core, "backbone"):
+        backbone = core.slow_net if teacher else core.backbone
+    if lut is not None and not torch.is_tensor(lut):
+        lut = torch.tensor(list(lut), dtype=torch.uint8, device=image.device)
+    with torch.no_grad():
+        logits = backbone._logits(image)
+        return ops.infer_labels(logits, image.shape[-2:], lut, want_conf)
 
 
 def validation_iou(net, batches, num_classes=19):

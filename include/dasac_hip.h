@@ -172,6 +172,11 @@ int dasac_ce_loss(const float* logits, const int64_t* labels, const float* class
                   const float* conf, int B, int C, int64_t HW, int mode, const float* gscale,
                   float* loss, float* dlogits, float* per_class, void* workspace, size_t ws_bytes,
                   dasac_stream_t stream);
+/* Inference (infer_val.py:160-163 and the result writer's argmax + trainId->labelId mapping, :60-65):
+ * labels[b,y,x] = lut[argmax_c softmax(bilinear_ac(logits))[b,c,y,x]] (lut null: the class index), optional
+ * conf = the winning probability.  1 (+4) bytes written per output pixel. */
+int dasac_infer_labels(const float* logits, int B, int C, int h, int w, int H, int W, const uint8_t* lut,
+                       uint8_t* labels, float* conf, dasac_stream_t stream);
 int dasac_warp_affine(const float* x, const float* theta, int B, int C, int H, int W, float* out,
                       dasac_stream_t stream);
 int dasac_warp_pool(const float* probs, const float* theta, const float* theta_inv, int N, int T,
@@ -209,6 +214,13 @@ int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t* argmax, in
                       int W, int OH, int OW, int k, int s, int pad, int relu_mask, float* dx,
                       dasac_stream_t stream);
 int dasac_ema_chunk_elems(void);
+/* torch.optim.SGD(momentum, no nesterov, dampening 0) over all parameters of up to 8 groups in ONE launch
+ * (base_trainer.py:63-66 over basenet.py:73-95):  d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf.
+ * tensors: device array of {float* p; const float* g; float* buf; int64 n; int64 group}; chunks as for
+ * dasac_ema_update ((tensor, chunk) pairs of dasac_ema_chunk_elems() elements); group_lr/group_wd: HOST arrays. */
+int dasac_sgd_step(const void* tensors, int n_tensors, const int32_t* chunks, int n_chunks,
+                   const float* group_lr, const float* group_wd, int n_groups, float momentum, int first,
+                   dasac_stream_t stream);
 int dasac_ema_update(const void* pairs, int n_tensors, const int32_t* chunks, int n_chunks,
                      float momentum, int update, double* sq, float* out, dasac_stream_t stream);
 int dasac_scale_planes(const float* x, const float* plane_scale, int64_t planes, int64_t HW,

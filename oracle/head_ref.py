@@ -306,3 +306,15 @@ def view_affines(params, crop_h, crop_w):
     inv[:, 1, 2] = -1 * (inv[:, 1, 0] * theta[:, 0, 2] + inv[:, 1, 1] * theta[:, 1, 2])
     inv /= torch.tensor([p[3] for p in params], dtype=torch.float32).view(-1, 1, 1) ** 2
     return theta, inv
+
+
+def infer_labels(logits, out_h, out_w, lut=None):
+    """/root/reference/infer_val.py:160-163 (`_, logits = model(image); masks_pred = F.softmax(logits, 1)`) followed by the
+    result writer's `argmax` over classes and `convert_to_cs` (infer_val.py:60-65, train id -> label id).
+    Returns (uint8 labels [B,H,W], winning probability [B,H,W], second-best gap [B,H,W])."""
+    up = upsample_bilinear_ac(logits, out_h, out_w)
+    probs = torch.softmax(up, dim=1)
+    top2 = probs.topk(2, dim=1).values
+    idx = probs.argmax(dim=1)
+    lab = idx if lut is None else lut.long()[idx]
+    return lab.to(torch.uint8), top2[:, 0], top2[:, 0] - top2[:, 1]

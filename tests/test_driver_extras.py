@@ -50,3 +50,48 @@ def test_iou_counts_kernel_matches_reference_definition():
         fp = int(((pred == c) & (gt != c) & valid).sum())
         fn = int(((pred != c) & (gt == c) & valid).sum())
         assert counts[:, c].tolist() == [2 * tp, 2 * fp, 2 * fn]
+
+
+@pytest.mark.gpu
+def test_fused_inference_labels_match_oracle():
+    """infer_val.py:160-163 + argmax + convert_to_cs as one kernel: label maps equal the oracle's except where the
+    top-2 probabilities are within fp32 noise of each other."""
+    import driver
+    from oracle import head_ref as R
+    from dasac_hip import ops
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(2, 19, 23, 31, generator=g) * 3
+    lut = torch.tensor(driver.CITYSCAPES_TRAIN_TO_ID, dtype=torch.uint8)
+    lab, conf = ops.infer_labels(logits.cuda(), (177, 241), lut.cuda(), want_conf=True)
+    ref_lab, ref_conf, gap = R.infer_labels(logits, 177, 241, lut)
+    assert lab.dtype == torch.uint8 and lab.shape == (2, 177, 241)
+    diff = lab.cpu() != ref_lab
+    assert int(diff.sum()) == int((diff & (gap < 1e-5)).sum())      # only exact near-ties may differ
+    assert float(diff.float().mean()) < 1e-4
+    assert float((conf.cpu() - ref_conf).abs().max()) < 1e-5
+    lab2, _ = ops.infer_labels(logits.cuda(), (177, 241))
+    assert torch.equal(lut.cuda()[lab2.long()], lab)
+    # a 5-class head goes through the generic instantiation
+    l5 = torch.randn(1, 5, 9, 7, generator=g)
+    lab5, _ = ops.infer_labels(l5.cuda(), (33, 29))
+    r5, _, gap5 = R.infer_labels(l5, 33, 29)
+    d5 = lab5.cpu() != r5
+    assert int(d5.sum()) == int((d5 & (gap5 < 1e-5)).sum())
+
+
+@pytest.mark.gpu
+def test_infer_label_maps_through_the_model():
+    import driver
+    import models
+    from types import SimpleNamespace as NS
+    from oracle.step_ref import DEFAULT_CFG
+    import torch.nn as nn
+    d = dict(DEFAULT_CFG)
+    d.update(INIT_MODEL="", OPT_NESTEROV=False)
+    net = models.get_model(NS(**d), 0, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none")).cuda().eval()
+    x = torch.randn(1, 3, 65, 81, device="cuda")
+    lab, _ = driver.infer_label_maps(net, x, lut=driver.CITYSCAPES_TRAIN_TO_ID)
+    with torch.no_grad():
+        _, up = net(x, teacher=False)
+    want = torch.tensor(driver.CITYSCAPES_TRAIN_TO_ID, device="cuda")[up.softmax(1).argmax(1)]
+    assert float((lab.long() != want).float().mean()) < 1e-3
