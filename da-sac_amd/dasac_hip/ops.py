@@ -548,6 +548,7 @@ def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
                                         invstd.data_ptr(), L.stream_ptr()), "dasac_bn_train_finalize")
     if upd:
         bn.num_batches_tracked += 1
+        bump_versions([bn.running_mean, bn.running_var])     # written through raw pointers; eval-mode folds key on them
     y = torch.empty_like(z)
     L.check(lib.dasac_bn_apply(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), int(relu), N, Cn, HW, y.data_ptr(),
                                L.stream_ptr()), "dasac_bn_apply")

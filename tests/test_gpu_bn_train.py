@@ -71,3 +71,28 @@ def test_baseline_adabn_iteration_vs_oracle():
     assert int(st["model.bn1.num_batches_tracked"]) == 2
     bad = sorted(((rel_err(st[k], ref.student[k].detach()), k) for k in N.trainable_keys(sd)), reverse=True)
     assert bad[len(bad) // 2][0] < 1e-5 and bad[0][0] < 1e-2, bad[:3]
+
+
+def test_eval_forward_after_train_mode_steps_uses_the_new_running_stats():
+    """AdaBN (train.py:281-289): train-mode forwards move the running statistics through the HIP kernels; the eval-mode
+    fold (cached per BN layer) has to follow."""
+    import models
+    net = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=False)
+    net.load_state_dict(N.resnet101_state(seed=9, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
+    net.cuda()
+    x = torch.randn(2, 3, 33, 41, device="cuda")
+    y = torch.zeros(2, 33, 41, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        net.eval()
+        e0, _ = net(x)
+        net.train()
+        for _ in range(2):
+            net(x * 3 + 1, y)
+        net.eval()
+        e1, _ = net(x)
+        fresh = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=False)
+        fresh.load_state_dict(net.state_dict(), strict=True)
+        fresh.cuda().eval()
+        e2, _ = fresh(x)
+    assert rel_err(e1, e0) > 1e-3
+    assert rel_err(e1, e2) < 1e-6
