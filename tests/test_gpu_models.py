@@ -177,3 +177,36 @@ def test_inference_paths_and_no_grad():
         logits, up = net(x, teacher=False)
         l2, up2 = net(x, teacher=True)
     assert logits.shape == (1, 19, 5, 7) and up.shape == (1, 19, 33, 49) and l2.shape == logits.shape
+
+
+def test_three_sac_iterations_with_teacher_updates_vs_oracle():
+    """train.py:266-298 three times with `update_teacher` on EVERY iteration (NET_MOMENTUM .5, 8x the reference LR so
+    that student and teacher visibly move): EMA kernel -> teacher forward -> pseudo labels -> fused SGD must track the
+    CPU oracle step by step (a teacher or student running on stale packed weights shows up from iteration 1 on)."""
+    import models
+    import driver
+    from oracle import step_ref as S
+    kw = dict(NET_MOMENTUM=0.5, LR=2e-3)
+    cfg = model_cfg(**kw)
+    sd = N.resnet101_state(seed=1, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2)
+    ref = S.SacOracle(sd, cfg=dict(S.DEFAULT_CFG, **kw))
+    ref_opt = S.SgdOracle(ref)
+    net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT)
+    net.backbone.load_state_dict(sd, strict=True)
+    net.cuda().train()
+    optim = driver.make_optimizer(net, cfg)
+    to = lambda ts: tuple(t.cuda() for t in ts)
+    seen = []
+    for it in range(3):
+        src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cpu", seed=20 + it)
+        ls_r, lt_r, outs_r = S.sac_train_iteration(ref, ref_opt, src, tuple(t.clone() for t in tgt), 2, True)
+        ls, lt, outs = driver.sac_train_iteration(net, optim, to(src), to(tgt), 2, True, cfg.LR_TARGET)
+        assert float(ls["loss_ce"]) == pytest.approx(ls_r["loss_ce"], rel=2e-3), it
+        assert float(lt["teacher_diff"]) == pytest.approx(lt_r["teacher_diff"], rel=2e-3, abs=1e-6), it
+        assert float(lt["self_ce"]) == pytest.approx(lt_r["self_ce"], rel=2e-2, abs=1e-5), it
+        mism = (outs["teacher_labels"].cpu() != outs_r["teacher_labels"]).float().mean()
+        assert float(mism) < 5e-3, (it, float(mism))
+        seen.append(float(lt["teacher_diff"]))
+    assert seen[0] == 0.0 and seen[1] > 0.0 and seen[2] > 0.0
+    w, w_ref = net.slow_net.state_dict()["model.layer4.2.conv3.weight"].cpu(), ref.teacher["model.layer4.2.conv3.weight"].detach()
+    assert rel_err(w, w_ref) < 1e-3
