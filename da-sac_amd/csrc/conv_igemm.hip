@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM convolution on the gfx950 matrix cores: exact fp32 (v_mfma_f32_32x32x2_f32, the default) or,
+// opt-in per call (template flag X3), split-bf16 products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 //
 // Replaces every nn.Conv2d call of the reference backbone (models/deeplabv2.py:59,65-66,70,107,
 // 122,147-148,262-263; models/fcn.py:49,53,57,78,88) -- 1x1, dilated 3x3, 7x7/2 stem, and the
@@ -10,12 +11,12 @@
 // `gather` is table driven: row k of the im2col matrix is (channel plane offset, dh, dw), so one
 // kernel covers any kernel size / dilation / padding / multi-branch layout; the table row is
 // wave-uniform (scalar loads), lanes run along pixels (coalesced NCHW reads).  Tiles go through
-// LDS ([k][m] / [k][pix], conflict-free ds_read_b32 in the MFMA operand pattern), register-staged
-// double buffering: the global loads of K-step t+1 are in flight while the 32..64 MFMAs of step t
-// issue.  The BN(eval) scale/shift, bias, residual add, ReLU and the ReLU-mask of the backward
+// LDS (k-interleaved 16-byte words, one conflict-free ds_read_b128 per operand and 4 MFMAs), register-staged
+// double buffering: the global loads of K-step t+1 are in flight while the MFMAs of step t issue.  The BN(eval) scale/shift, bias, residual add, ReLU and the ReLU-mask of the backward
 // pass are folded into the epilogue ("ABN": conv+BN+ReLU in one pass, no extra HBM round trip).
 //
-// Roofline: MFMA-bound, 2*M*Npix*K flops per launch against the 157.3 TFLOP/s fp32 matrix peak.
+// Roofline: MFMA-bound, 2*M*Npix*K flops per launch against the 157.3 TFLOP/s fp32 matrix peak
+// (X3: three bf16 MFMAs per product -> 2500/3 TFLOP/s equivalent; today limited by the fp32 -> LDS staging).
 #include "common.hpp"
 
 #include <cstdlib>
@@ -805,14 +806,14 @@ static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, 
 constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
 constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8
 
-// stream-K pays when the tile count leaves the last round of resident blocks (3 per CU for the plain
-// kernel) mostly empty
+// stream-K pays when the tile count leaves the last round of resident blocks mostly empty
 static bool want_streamk(int tiles, int k_steps) {
   static const int mode = getenv("DASAC_STREAMK") ? atoi(getenv("DASAC_STREAMK")) : 1;   // 0 off, 1 auto, 2 always
   if (mode == 0 || tiles < kSkWorkers) return false;
   if (mode == 2) return true;
-  // measured: the persistent schedule (2 workers/CU) wins on long contractions whose tile count fills the
-  // last round of the plain launch badly; short-K 1x1 layers are better off with 3 plain blocks per CU.
+  // measured: the persistent schedule (3 workers/CU, <=168 registers) wins on long contractions whose tile count
+  // fills the last round of the plain launch badly; short-K 1x1 layers are better off with the plain kernel's
+  // 4 blocks per CU (128 registers) even with a partly empty last round (85 vs 99 TFLOP/s at K = 256).
   const int resident = kNumCu * 3;
   const int rounds = (tiles + resident - 1) / resident;
   return k_steps >= 64 && (double)tiles / ((double)rounds * resident) < 0.93;
