@@ -104,8 +104,8 @@ def main():
     from dasac_hip import ops
 
     cfg = model_cfg(arch, baseline)
-    if rank != 0:
-        sys.stdout = open(os.devnull, "w")
+    # stdout carries exactly ONE line (the JSON); the model constructors' progress prints go to stderr on rank 0
+    sys.stdout = sys.stderr if rank == 0 else open(os.devnull, "w")
     net = models.get_model(cfg, local, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
     driver.init_synthetic_weights(net, seed=0)
     net.cuda(local).train()
@@ -171,7 +171,6 @@ def main():
     labelled = float((out[2]["teacher_labels"] != 255).float().mean()) if out[2] is not None else 0.0
 
     if rank == 0:
-        sys.stdout = sys.__stdout__
         gemm = {k: v for k, v in prof.items() if k.startswith("conv_gemm")}
         dom_name = max(gemm, key=lambda k: gemm[k]["seconds"]) if gemm else "conv_gemm"
         dom = gemm.get(dom_name, {"flops": 0.0, "seconds": 1.0, "launches": 0})
@@ -210,6 +209,7 @@ def main():
             line["alt"] = alt
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
             line["cpu_baseline"] = cpu_baseline(args.size)
+        sys.stdout = sys.__stdout__
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

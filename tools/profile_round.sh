@@ -12,7 +12,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-alt"
-python $R/bench.py > $O/bench.json 2> $O/bench.err
+python $R/bench.py > $O/bench.json 2> $O/bench.err   # stdout = the one JSON line
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o kt -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 python $R/tools/rocpd_stats.py /tmp/p1/kt_results.db > $O/kernel_stats.md
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d /tmp/p2 -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
