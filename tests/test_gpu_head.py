@@ -163,3 +163,41 @@ def test_bn_fold_channel_sums_ema():
         assert rel_err(out, ref) < 1e-6
         for a, b in zip(sd, slow):
             assert rel_err(a, b) < 1e-6
+
+
+def test_full_size_head_properties():
+    """cfg-3 size ([8,19,97,97] -> [8,19,769,769]): size-independent properties of the head kernels."""
+    import math
+    from dasac_hip import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, C, h, H = 8, 19, 97, 769
+    logits = torch.randn(B, C, h, h, device="cuda", generator=g) * 3
+    up, probs, sums = ops.upsample_softmax(logits, (H, H), want_up=True, want_probs=True, want_sums=True)
+    # softmax rows sum to one; the class prior sums add up to the pixel count
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-5
+    assert float(sums.sum()) == pytest.approx(B * H * H, rel=1e-6)
+    # interpolation never leaves the range of its four taps, and reproduces the corners exactly (align_corners=True)
+    assert float(up.max()) <= float(logits.max()) and float(up.min()) >= float(logits.min())
+    assert torch.equal(up[:, :, 0, 0], logits[:, :, 0, 0]) and torch.equal(up[:, :, -1, -1], logits[:, :, -1, -1])
+    # constant planes stay constant; uniform logits cost log(C) on every labelled pixel, 0 on ignored ones
+    const = torch.arange(C, device="cuda", dtype=torch.float32).view(1, C, 1, 1).expand(B, C, h, h).contiguous()
+    upc, _, _ = ops.upsample_softmax(const, (H, H))
+    assert float((upc - torch.arange(C, device="cuda").view(1, C, 1, 1)).abs().max()) < 1e-5
+    labels = torch.randint(0, C, (B, H, H), device="cuda", generator=g)
+    labels[:, :16] = 255
+    loss, _, _ = ops.ce_loss(torch.zeros(B, C, H, H, device="cuda"), labels)
+    assert float(loss) == pytest.approx(math.log(C) * (H - 16) / H, rel=1e-5)
+    # gradient of the mean CE sums to zero over the classes of every pixel
+    _, dl, _ = ops.ce_loss(up, labels, want_grad=True)
+    assert float(dl.sum(1).abs().max()) < 1e-9 + 1e-6 * float(dl.abs().max())
+    # identity affines: warping is the identity up to the fp32 round-off of affine_grid's normalised coordinates
+    # (sample positions land within ~1e-4 px of the pixel centres), pooling T identical views returns the view,
+    # warp-back returns it again
+    eye = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], device="cuda").repeat(B, 1, 1)
+    assert float((ops.warp_affine(probs, eye) - probs).abs().max()) < 1e-3
+    same = probs[:2].repeat_interleave(4, dim=0).contiguous()            # 2 groups x 4 identical views
+    pooled, mask, aligned = ops.warp_pool(same, eye, eye, 4)
+    assert float((aligned - same).abs().max()) < 1e-3 and float(mask.min()) == 1.0
+    assert float((pooled - probs[:2]).abs().max()) < 1e-3
+    back = ops.warp_back(pooled, mask, eye, 4)
+    assert float((back - same).abs().max()) < 2e-3
