@@ -158,10 +158,12 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
   const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
   int it, it_end;                                            // (tile, K-step) space: tiles*KT < 2^31 (checked by the host)
   int my_range = 0;
+  long long sk_total = 0;
   if (STREAMK) {
     const int G = gridDim.x;                                 // multiple of 8
     my_range = xcd * (G / kNumXcd) + slot;
     const long long total = (long long)m_tiles * n_tiles * KT;
+    sk_total = total;
     it = (int)(total * my_range / G);
     it_end = (int)(total * (my_range + 1) / G);
   } else {
@@ -339,26 +341,35 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
           __hip_atomic_store(&flags[my_range], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       } else if (ke < KT) {
-        // I hold the FIRST K-steps; the rest was deposited by the next range at the start of its work.
-        if (t == 0) {
-          int spins = 0;
-          while (__hip_atomic_load(&flags[my_range + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1 << 26)) {
-            __builtin_amdgcn_s_sleep(8);
-            ++spins;
+        // I hold the FIRST K-steps; the rest was deposited by the following range(s), each at the very start of
+        // its work (a range shorter than a tile -- fewer tiles than workers -- makes several of them contribute).
+        const int G = gridDim.x;
+        const long long tile_end = (long long)(tile + 1) * KT;
+        for (int r = my_range + 1; r < G; ++r) {
+          const long long r_begin = sk_total * r / G, r_end = sk_total * (r + 1) / G;
+          if (r_end > r_begin) {                               // an empty range deposits nothing
+            if (t == 0) {
+              int spins = 0;
+              while (__hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1 << 26)) {
+                __builtin_amdgcn_s_sleep(8);
+                ++spins;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const int src0 = r * (ACC_REGS * kThreads * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr)
+                  acc[i][j][rr] += buf_f32(rpart, (unsigned)t * 4u, src0 + ((i * TN + j) * 16 + rr) * kThreads * 4);
+                asm volatile("" ::: "memory");
+              }
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if (r_end >= tile_end) break;                        // that range reached the end of my tile
         }
-        __syncthreads();
-        const int src0 = (my_range + 1) * (ACC_REGS * kThreads * 4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              acc[i][j][r] += buf_f32(rpart, (unsigned)t * 4u, src0 + ((i * TN + j) * 16 + r) * kThreads * 4);
-            asm volatile("" ::: "memory");
-          }
       }
     }
 
@@ -809,14 +820,16 @@ constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8
 // stream-K pays when the tile count leaves the last round of resident blocks mostly empty
 static bool want_streamk(int tiles, int k_steps) {
   static const int mode = getenv("DASAC_STREAMK") ? atoi(getenv("DASAC_STREAMK")) : 1;   // 0 off, 1 auto, 2 always
-  if (mode == 0 || tiles < kSkWorkers) return false;
+  if (mode == 0 || (long long)tiles * k_steps < kSkWorkers) return false;               // every range gets >= 1 K-step
   if (mode == 2) return true;
   // measured: the persistent schedule (3 workers/CU, <=168 registers) wins on long contractions whose tile count
   // fills the last round of the plain launch badly; short-K 1x1 layers are better off with the plain kernel's
-  // 4 blocks per CU (128 registers) even with a partly empty last round (85 vs 99 TFLOP/s at K = 256).
+  // 4 blocks per CU (128 registers) even with a partly empty last round (85 vs 99 TFLOP/s at K = 256) -- unless
+  // the launch would leave most of the chip idle (small batches: 296 tiles at B = 2, 148 at B = 1).
   const int resident = kNumCu * 3;
   const int rounds = (tiles + resident - 1) / resident;
-  return k_steps >= 64 && (double)tiles / ((double)rounds * resident) < 0.93;
+  const double eff = (double)tiles / ((double)rounds * resident);
+  return k_steps >= 64 ? eff < 0.93 : (k_steps >= 16 && eff < 0.6);
 }
 
 template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool X3 = false>

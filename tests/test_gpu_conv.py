@@ -130,3 +130,40 @@ def test_resnet_shapes_full_size_linearity():
         n, co, oh, ow = i % 8, (37 * i) % 256, (11 * i) % 97, (29 * i + 3) % 97
         patch = xp[n, :, oh:oh + 5:2, ow:ow + 5:2]
         assert abs(float((patch * wc[co]).sum()) - float(yc[n, co, oh, ow])) < 1e-4
+
+
+SMALL_BATCH = [
+    # name, cin, cout, branch, (N, H, W): fewer 128x128 tiles than persistent workers -> several ranges contribute to a tile
+    ("l3_3x3_b2", 256, 256, (3, 3, 2, 2), (2, 97, 97)),          # 296 tiles x 144 K-steps over 768 workers
+    ("l3_3x3_b1", 256, 256, (3, 3, 2, 2), (1, 97, 97)),          # 148 tiles: ~5 ranges per tile
+    ("l3_1x1_b1", 1024, 256, (1, 1, 1, 0), (1, 97, 97)),         # 64 K-steps
+    ("l3_1x1_short_k_b1", 256, 1024, (1, 1, 1, 0), (1, 97, 97)),  # 16 K-steps, 592 tiles: stays tile-per-block
+    ("l4_3x3_b1_odd", 512, 512, (3, 3, 4, 4), (1, 61, 53)),      # ragged last pixel tile
+]
+
+
+@pytest.mark.parametrize("case", SMALL_BATCH, ids=[c[0] for c in SMALL_BATCH])
+def test_small_batch_stream_k_with_several_contributors(case):
+    """Inference / cfg-2 sized launches: the persistent schedule cuts a tile into more than two ranges; the worker
+    holding its first K-steps sums the deposits of all the following ones."""
+    from dasac_hip import ops
+    name, cin, cout, br, (N, H, W) = case
+    spec = ops.ConvSpec(cin, cout, [br], 1)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, br[0], br[1], generator=g) / (cin * br[0] * br[1]) ** 0.5
+    shift = torch.randn(cout, generator=g)
+    res = torch.randn(N, cout, H, W, generator=g)
+    dz = torch.randn(N, cout, H, W, generator=g)
+    yr = torch.relu(F.conv2d(x.double(), w.double(), None, 1, br[3], br[2]) + shift.double().view(1, -1, 1, 1) + res.double())
+    dxr = F.conv_transpose2d(dz.double(), w.double(), None, 1, br[3], 0, 1, br[2])
+    y = ops.conv_forward(spec, x.cuda(), [w.cuda()], shift=shift.cuda(), res=res.cuda(), relu=True)
+    assert rel_err(y.double().cpu(), yr) < TOL
+    dx = ops.conv_dgrad(spec, dz.cuda(), [w.cuda()], (H, W))
+    assert rel_err(dx.double().cpu(), dxr) < TOL
+    ops.set_precision("bf16x3")
+    try:
+        y3 = ops.conv_forward(spec, x.cuda(), [w.cuda()], shift=shift.cuda(), res=res.cuda(), relu=True)
+    finally:
+        ops.set_precision("fp32")
+    assert rel_err(y3.double().cpu(), yr) < TOL
