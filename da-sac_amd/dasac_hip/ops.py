@@ -176,15 +176,24 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     for t_ in (res, mask):
         assert t_ is None or (t_.shape == out.shape and t_.is_contiguous())
     ws = L.workspace(lib.dasac_conv_gemm_workspace(), x.device)
-    span = "conv_gemm"
-    if PROFILE.on:
-        span = "conv_gemm<stream-K>" if lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K) else "conv_gemm<tile-per-block>"
-    with PROFILE.span(span, 2.0 * Nb * OH * OW * M * K, (M, K, Nb * OH * OW, stride, ostride, res is not None, mask is not None)):
-        fn = lib.dasac_conv_gemm_x3 if getattr(packed, "dasac_x3", False) else lib.dasac_conv_gemm
-        L.check(fn(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
-                   stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
-                   L.ptr(mask), int(relu), L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr()),
-                "dasac_conv_gemm")
+    fn = lib.dasac_conv_gemm_x3 if getattr(packed, "dasac_x3", False) else lib.dasac_conv_gemm
+    tag = (M, K, Nb * OH * OW, stride, ostride, res is not None, mask is not None)
+
+    def launch(span, pix_begin, pix_count, schedule):
+        n = pix_count if pix_count else Nb * OH * OW - pix_begin
+        with PROFILE.span(span, 2.0 * n * M * K, tag):
+            L.check(fn(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
+                       stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
+                       L.ptr(mask), int(relu), pix_begin, pix_count, schedule, L.ptr(ws), 0 if ws is None else ws.numel(),
+                       L.stream_ptr()), "dasac_conv_gemm")
+
+    lead = lib.dasac_conv_gemm_plan(Nb, OH, OW, M, K)
+    if lead > 0:        # whole rounds one block per tile (lockstep over K: halo rows shared in L2), the rest stream-K
+        launch("conv_gemm<tile-per-block>", 0, lead, 1)
+        launch("conv_gemm<stream-K>", lead, 0, 0)
+    else:
+        sk = PROFILE.on and lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K)
+        launch("conv_gemm<stream-K>" if sk else "conv_gemm<tile-per-block>", 0, 0, 0)
     return out
 
 

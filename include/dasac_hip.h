@@ -72,7 +72,10 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *                    against scale*W, so the epilogue only adds the shift.
  *                    Call once per branch (tap0 = first tap of the branch, total_taps = all).
  * dasac_conv_gemm    out[n,m,oh*os,ow*os] = epi( sum_k packed[k][m] * x[n, c, oh*stride+dh, ow*stride+dw] )
- *                    epi: v + shift[m] (+res) (ReLU) (zeroed where mask <= 0).  With a workspace of
+ *                    epi: v + shift[m] (+res) (ReLU) (zeroed where mask <= 0).  The launch covers the
+ *                    output pixels [pix_begin, pix_begin + pix_count) of the flattened (n, oh, ow) grid
+ *                    (whole 128-pixel tiles; pix_count 0 = to the end); schedule 0 = pick, 1 = one block
+ *                    per tile, 2 = persistent stream-K.  With a workspace of
  *                    dasac_conv_gemm_workspace() bytes the launcher may pick the persistent stream-K
  *                    schedule (equal matrix work per CU); workspace NULL = one block per tile.
  * dasac_conv_wgrad   partial weight gradients (split over pixels) into `workspace`;
@@ -92,7 +95,8 @@ int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, f
                     int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                     int OutH, int OutW, int ostride,
                     const float* shift, const float* res, const float* mask,
-                    int relu, void* workspace, size_t ws_bytes, dasac_stream_t stream);
+                    int relu, int pix_begin, int pix_count, int schedule,
+                    void* workspace, size_t ws_bytes, dasac_stream_t stream);
 /* Split-bf16 ("bf16x3") variant of the same contraction: every fp32 operand x is split into
  * head = bf16(x) and tail = bf16(x - head) and x*y is evaluated as xh*yh + xh*yl + xl*yh on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error of a product <= ~2^-15, typically
@@ -105,9 +109,12 @@ int dasac_conv_gemm_x3(const float* x, const void* packed_x3, const int32_t* tab
                        int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                        int OutH, int OutW, int ostride,
                        const float* shift, const float* res, const float* mask,
-                       int relu, void* workspace, size_t ws_bytes, dasac_stream_t stream);
+                       int relu, int pix_begin, int pix_count, int schedule,
+                       void* workspace, size_t ws_bytes, dasac_stream_t stream);
 size_t dasac_conv_gemm_workspace(void);
 int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K);   /* 1 = stream-K, 0 = one block per tile */
+/* > 0: issue the conv as two launches -- pixels [0, n) with schedule 1, the rest with schedule 0 (see conv_igemm.hip) */
+int dasac_conv_gemm_plan(int Nb, int OH, int OW, int M, int K);
 size_t dasac_conv_wgrad_workspace(int Nb, int OH, int OW, int M, int K);
 int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
                      int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
