@@ -461,7 +461,7 @@ template <int BM, int BN, int WAVES_M, bool FAST, bool X3>
 __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
                                                        float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
-                                                       int pix_per_split) {
+                                                       int n_splits, int pix_per_split) {
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -473,7 +473,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
   __shared__ __attribute__((aligned(16))) float sA[1][X3 ? 32 * PA : BM * kWgPitch];   // X3: [head|tail][4 octets][PA] x 16 B
   __shared__ __attribute__((aligned(16))) float sB[1][X3 ? 32 * PB : BN * kWgPitch];
 
-  const int tile = blockIdx.x % (m_tiles * k_tiles), split = blockIdx.x / (m_tiles * k_tiles);
+  // block b runs on XCD b % 8: give every XCD a CONTIGUOUS run of the (split-major) block list, so that the tiles of a
+  // pixel split -- which all stream the same dZ and X pixels -- meet in one L2 instead of being fetched by all eight
+  const int n_blocks = m_tiles * k_tiles * n_splits;
+  const int per_xcd = (n_blocks + kNumXcd - 1) / kNumXcd;
+  const int lb = ((int)blockIdx.x % kNumXcd) * per_xcd + (int)blockIdx.x / kNumXcd;
+  if (lb >= n_blocks) return;
+  const int tile = lb % (m_tiles * k_tiles), split = lb / (m_tiles * k_tiles);
   const int m_tile = tile % m_tiles, k_tile = tile / m_tiles;
   const int m0 = m_tile * BM, kb0 = k_tile * BN;
   const int t = threadIdx.x, lane = t & 63;
@@ -861,12 +867,13 @@ template <int BM, int BN, int WAVES_M, bool FAST>
 static void launch_wgrad(bool x3, const float* dZ, const float* X, const int4* tab, float* P, float* Psum, const GemmGeom& g,
                          int splits, int pix_per_split, hipStream_t s) {
   const int m_tiles = g.Mpad / BM, k_tiles = g.Kpad / BN;
+  const int grid = (m_tiles * k_tiles * splits + kNumXcd - 1) / kNumXcd * kNumXcd;
   if (x3)
-    hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST, true>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P,
-                       Psum, g, m_tiles, k_tiles, pix_per_split);
+    hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST, true>), dim3(grid), dim3(kThreads), 0, s, dZ, X, tab, P,
+                       Psum, g, m_tiles, k_tiles, splits, pix_per_split);
   else
-    hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST, false>), dim3(m_tiles * k_tiles * splits), dim3(kThreads), 0, s, dZ, X, tab, P,
-                       Psum, g, m_tiles, k_tiles, pix_per_split);
+    hipLaunchKernelGGL((conv_wgrad<BM, BN, WAVES_M, FAST, false>), dim3(grid), dim3(kThreads), 0, s, dZ, X, tab, P,
+                       Psum, g, m_tiles, k_tiles, splits, pix_per_split);
 }
 
 }  // namespace dasac
