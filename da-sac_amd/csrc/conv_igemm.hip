@@ -763,6 +763,21 @@ __global__ void pack_x3(const f32x4* Wp, f32x4* Wx, int Mpad, int Kpad) {   // W
   }
 }
 
+// sum over the pixel splits of one slab element: four independent chains so that the loads of several slabs are in
+// flight together (the slabs are 1-64 separate HBM streams)
+__device__ __forceinline__ float sum_splits(const float* __restrict__ p, size_t slab, int splits) {
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {
+    g0 += p[(size_t)s * slab];
+    g1 += p[(size_t)(s + 1) * slab];
+    g2 += p[(size_t)(s + 2) * slab];
+    g3 += p[(size_t)(s + 3) * slab];
+  }
+  for (; s < splits; ++s) g0 += p[(size_t)s * slab];
+  return (g0 + g1) + (g2 + g3);
+}
+
 // dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G)
 // grid (chunks of 1024 k, output channels); the dot term is combined with one float atomic per block.
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P, const float* __restrict__ Psum, int splits,
@@ -786,8 +801,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P,
     if (i < n) {
       const int tap = i / Cin, ci = i - tap * Cin;
       const size_t kidx = (size_t)co * Kpad + (size_t)(tap0 + tap) * Cin + ci;
-      float gsum = 0.f;
-      for (int s = 0; s < splits; ++s) gsum += P[s * slab + kidx];
+      const float gsum = sum_splits(P + kidx, slab, splits);
       const size_t widx = ((size_t)co * Cin + ci) * taps + tap;
       if (dot) part += gsum * Wt[widx];
       dW[widx] = gsum * sc;
@@ -1210,9 +1224,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_expanded(const float* __rest
     const int64_t r = i / Cin;
     const int tap = (int)(r % taps), co = (int)(r / taps);
     const size_t idx = (size_t)((tap0 + tap) * Cp + co) * Kpad + ci;
-    float g = 0.f;
-    for (int s = 0; s < splits; ++s) g += P[s * slab + idx];
-    dW[((size_t)co * Cin + ci) * taps + tap] = g;
+    dW[((size_t)co * Cin + ci) * taps + tap] = sum_splits(P + idx, slab, splits);
   }
 }
 
