@@ -839,8 +839,22 @@ constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 w
 constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8
 
 // stream-K pays when the tile count leaves the last round of resident blocks mostly empty
+// The persistent schedule waits on other workers inside the launch, so all of them must be resident at once:
+// 3 per CU on the 256 CUs this library is written for.  A device with fewer CUs (partitioned / other part) gets the
+// tile-per-block schedule only.
+static bool persistent_grid_fits() {
+  static const int ok = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus >= kNumCu ? 1 : 0;
+  }();
+  return ok != 0;
+}
+
 static bool want_streamk(int tiles, int k_steps) {
   static const int mode = getenv("DASAC_STREAMK") ? atoi(getenv("DASAC_STREAMK")) : 1;   // 0 off, 1 auto, 2 always
+  if (!persistent_grid_fits()) return false;
   if (mode == 0 || (long long)tiles * k_steps < kSkWorkers) return false;               // every range gets >= 1 K-step
   if (mode == 2) return true;
   // measured: the persistent schedule (3 workers/CU, <=168 registers) wins on long contractions whose tile count
@@ -859,7 +873,7 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
                        const Epilogue& ep, int n_tiles, int schedule, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
   if ((long long)m_tiles * (n_tiles + kNumXcd) * (g.Kpad / BK) >= (1ll << 31)) return fail(DASAC_EINVAL, "conv_gemm: iteration space exceeds 2^31");
-  const bool sk_ok = BM == 128 && workspace && (long long)m_tiles * n_tiles * (g.Kpad / BK) >= kSkWorkers;
+  const bool sk_ok = BM == 128 && workspace && (long long)m_tiles * n_tiles * (g.Kpad / BK) >= kSkWorkers && persistent_grid_fits();
   if (sk_ok && (schedule == 2 || (schedule == 0 && want_streamk(m_tiles * n_tiles, g.Kpad / BK)))) {
     const size_t part_bytes = (size_t)kSkWorkers * (BM * BN) * sizeof(float);
     const size_t need = part_bytes + (size_t)(kSkWorkers + 1) * sizeof(int);
