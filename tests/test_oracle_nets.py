@@ -123,3 +123,43 @@ def test_g11_view_sharding_index_tables():
     assert [gather_index(4, r, 2, 4) for r in range(4)] == [(0, 2), (0, 2), (2, 4), (2, 4)]
     assert [gather_index(8, r, 1, 4)[0] for r in range(8)] == [0, 0, 0, 0, 4, 4, 4, 4]
     assert gather_index(8, 0, 8, 4) is None
+
+
+def test_aten_conv_bn_pool_equal_the_textbook_definitions():
+    """The oracle delegates conv / BN / max-pool arithmetic to ATen (the reference's own provider).  Pin ATen itself
+    against explicit numpy loops on a small dilated, strided, padded case so that nothing in the chain is taken on trust."""
+    import numpy as np
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 7, 9)).astype(np.float64)
+    w = rng.standard_normal((4, 3, 3, 3)).astype(np.float64)
+    stride, pad, dil = 2, 2, 2
+    OH = (7 + 2 * pad - dil * 2 - 1) // stride + 1
+    OW = (9 + 2 * pad - dil * 2 - 1) // stride + 1
+    ref = np.zeros((2, 4, OH, OW))
+    for n in range(2):
+        for co in range(4):
+            for oh in range(OH):
+                for ow in range(OW):
+                    acc = 0.0
+                    for ci in range(3):
+                        for kh in range(3):
+                            for kw in range(3):
+                                ih, iw = oh * stride - pad + kh * dil, ow * stride - pad + kw * dil
+                                if 0 <= ih < 7 and 0 <= iw < 9:
+                                    acc += x[n, ci, ih, iw] * w[co, ci, kh, kw]
+                    ref[n, co, oh, ow] = acc
+    got = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, stride, pad, dil).numpy()
+    assert np.abs(got - ref).max() < 1e-12
+    # eval-mode BN and the ceil-mode 3x3/2 max-pool of the stem (deeplabv2.py:126)
+    g, b, m, v = (rng.standard_normal(3) for _ in range(4))
+    v = np.abs(v) + 0.5
+    bn = F.batch_norm(torch.from_numpy(x), torch.from_numpy(m), torch.from_numpy(v), torch.from_numpy(g), torch.from_numpy(b), False, 0.0, 1e-5)
+    want = (x - m[None, :, None, None]) / np.sqrt(v[None, :, None, None] + 1e-5) * g[None, :, None, None] + b[None, :, None, None]
+    assert np.abs(bn.numpy() - want).max() < 1e-12
+    mp = F.max_pool2d(torch.from_numpy(x), 3, 2, 1, ceil_mode=True).numpy()
+    PH, PW = mp.shape[2:]
+    for oh in range(PH):
+        for ow in range(PW):
+            win = x[:, :, max(oh * 2 - 1, 0):min(oh * 2 + 2, 7), max(ow * 2 - 1, 0):min(ow * 2 + 2, 9)]
+            assert np.array_equal(mp[:, :, oh, ow], win.max(axis=(2, 3)))
