@@ -19,6 +19,7 @@
 // (X3: three bf16 MFMAs per product -> 2500/3 TFLOP/s equivalent; today limited by the fp32 -> LDS staging).
 #include "common.hpp"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace dasac {
@@ -107,7 +108,8 @@ __device__ __forceinline__ void split_bf16(f32x4 v0, f32x4 v1, f32x4& heads, f32
 // contiguous ranges, one per worker, so every CU gets the same amount of matrix work no matter how the
 // tile count divides by the CU count (1178 tiles on 256 CUs would otherwise run 5 "rounds" for 4.6 of
 // work).  A tile cut by a range boundary is finished by the worker holding its FIRST K-steps (it reaches
-// them last); the other worker deposits its accumulators in `partial` as soon as it has them and raises
+// them last); the other worker deposits its accumulators in `partial` as soon as it has them -- at the very start
+// of its range, before it waits for anything itself, so no co-residency of all workers is required -- and raises
 // a flag (agent-scope release/acquire, placement independent).
 template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3>
 __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
@@ -350,10 +352,14 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
           const long long r_begin = sk_total * r / G, r_end = sk_total * (r + 1) / G;
           if (r_end > r_begin) {                               // an empty range deposits nothing
             if (t == 0) {
+              // Progress does not need all workers resident: a range deposits at the very START of its work, before it
+              // waits for anything, and blocks are dispatched in id order, so the depositor of r is at worst the next
+              // block to get a slot.  A wait that still outlasts ~2^26 sleeps (seconds) means the depositor died:
+              // abort the kernel (the stream reports a launch failure) instead of summing a slot that was never written.
               int spins = 0;
-              while (__hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1 << 26)) {
+              while (__hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 __builtin_amdgcn_s_sleep(8);
-                ++spins;
+                if (++spins >= (1 << 26)) __builtin_trap();
               }
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
@@ -838,18 +844,22 @@ static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, 
 constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
 constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8
 
-// stream-K pays when the tile count leaves the last round of resident blocks mostly empty
-// The persistent schedule waits on other workers inside the launch, so all of them must be resident at once:
-// 3 per CU on the 256 CUs this library is written for.  A device with fewer CUs (partitioned / other part) gets the
-// tile-per-block schedule only.
+// stream-K pays when the tile count leaves the last round of resident blocks mostly empty.
+// The persistent grid (3 workers per CU x 256 CUs) and the XCD mapping are sized for the full MI355X; a device with
+// fewer CUs (partitioned modes, other parts) gets the tile-per-block schedule only.  The answer is per device id
+// (a process may drive several devices / switch with hipSetDevice).
 static bool persistent_grid_fits() {
-  static const int ok = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return cus >= kNumCu ? 1 : 0;
-  }();
-  return ok != 0;
+  constexpr int kMaxDev = 64;
+  static std::atomic<signed char> cache[kMaxDev];          // 0 unknown, 1 fits, -1 does not
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const bool cached = dev >= 0 && dev < kMaxDev;
+  if (cached && cache[dev].load(std::memory_order_relaxed) != 0) return cache[dev].load(std::memory_order_relaxed) > 0;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  const bool ok = cus >= kNumCu;
+  if (cached) cache[dev].store(ok ? 1 : -1, std::memory_order_relaxed);
+  return ok;
 }
 
 static bool want_streamk(int tiles, int k_steps) {

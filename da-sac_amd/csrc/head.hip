@@ -362,20 +362,29 @@ __global__ __launch_bounds__(kHB) void warp_pool(const float* __restrict__ probs
     float best_ent = INFINITY, zsum = 0.f;
     for (int t = 0; t < T; ++t) {
       const int b = n * T + t;
-      const Sample s = make_sample(theta + b * 6, oy, ox, H, W);
-      const Sample si = make_sample(theta_inv + b * 6, oy, ox, H, W);
-      const float cov = si.w00 + si.w01 + si.w10 + si.w11;
       float v[kMaxC];
       float vs = 0.f;
+      if (theta) {
+        const Sample s = make_sample(theta + b * 6, oy, ox, H, W);
+        const Sample si = make_sample(theta_inv + b * 6, oy, ox, H, W);
+        const float cov = si.w00 + si.w01 + si.w10 + si.w11;
 #pragma unroll
-      for (int c = 0; c < kMaxC; ++c)
-        if (c < C) {
-          const size_t pb = ((size_t)b * C + c) * HW;
-          const float a = take(probs + pb, s);
-          if (aligned) aligned[pb + p] = a;
-          v[c] = a * cov;
-          vs += v[c];
-        }
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) {
+            const size_t pb = ((size_t)b * C + c) * HW;
+            const float a = take(probs + pb, s);
+            if (aligned) aligned[pb + p] = a;
+            v[c] = a * cov;
+            vs += v[c];
+          }
+      } else {   // views already aligned and coverage-weighted by the caller (SAC._avg_pool / _minentropy_pool on their own)
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) {
+            v[c] = probs[((size_t)b * C + c) * HW + p];
+            vs += v[c];
+          }
+      }
       if (mode == 0) {
 #pragma unroll
         for (int c = 0; c < kMaxC; ++c)
@@ -554,7 +563,7 @@ extern "C" int dasac_warp_affine(const float* x, const float* theta, int B, int 
 extern "C" int dasac_warp_pool(const float* probs, const float* theta, const float* theta_inv, int N, int T, int C, int H,
                                int W, int mode, float tolerance, float* aligned, float* pooled, float* mask,
                                dasac_stream_t stream) {
-  DASAC_REQUIRE(probs && theta && theta_inv && pooled && mask, "warp_pool: null pointer");
+  DASAC_REQUIRE(probs && pooled && mask && ((theta && theta_inv) || (!theta && !theta_inv && !aligned)), "warp_pool: null pointer");
   DASAC_REQUIRE(N > 0 && T > 0 && C > 0 && C <= kMaxC && (mode == 0 || mode == 1), "warp_pool: bad arguments");
   const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + N - 1) / N);
   hipLaunchKernelGGL(warp_pool, dim3(per * N), dim3(kHB), 0, as_stream(stream), probs, theta, theta_inv, T, C, H, W, mode,

@@ -354,13 +354,15 @@ __global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int
 }
 
 // batch mean / biased var -> scale, shift, mean, invstd; running stats: momentum update with the unbiased var
-__global__ void bn_train_finalize(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+__global__ void bn_train_finalize(const double* __restrict__ sums, double count_host, const double* __restrict__ count_dev,
+                                  const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float* __restrict__ running_mean,
                                   float* __restrict__ running_var, float momentum, float eps, int C,
                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                   float* __restrict__ invstd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  const double count = count_dev ? count_dev[0] : count_host;   // SyncBN: the all-reduced count stays on the device
   const double m = sums[c] / count;
   double var = sums[C + c] / count - m * m;
   if (var < 0) var = 0;
@@ -423,7 +425,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ d
 __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ z,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     const float* __restrict__ gamma, const double* __restrict__ sums,
-                                                    double count, int C, int HW, float* __restrict__ dz, int64_t total) {
+                                                    double count_host, const double* __restrict__ count_dev, int C, int HW,
+                                                    float* __restrict__ dz, int64_t total) {
+  const double count = count_dev ? count_dev[0] : count_host;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)((i / HW) % C);
     const float is = invstd[c];
@@ -451,11 +455,12 @@ extern "C" int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* 
   return DASAC_OK;
 }
 
-extern "C" int dasac_bn_train_finalize(const double* sums, double count, const float* gamma, const float* beta,
-                                       float* running_mean, float* running_var, float momentum, float eps, int C,
-                                       float* scale, float* shift, float* mean, float* invstd, dasac_stream_t stream) {
-  DASAC_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0, "bn_train_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_train_finalize, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, gamma, beta,
+extern "C" int dasac_bn_train_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                       int C, float* scale, float* shift, float* mean, float* invstd, dasac_stream_t stream) {
+  DASAC_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && (count > 0 || count_dev),
+                "bn_train_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_train_finalize, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, count_dev, gamma, beta,
                      running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd);
   DASAC_CHECK_LAUNCH("bn_train_finalize");
   return DASAC_OK;
@@ -483,13 +488,13 @@ extern "C" int dasac_bn_bwd_reduce(const float* dy, const float* z, const float*
 }
 
 extern "C" int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const float* invstd,
-                                  const float* gamma, const double* sums, double count, int N, int C, int64_t HW, float* dz,
-                                  float* dgamma, float* dbeta, dasac_stream_t stream) {
-  DASAC_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && count > 0, "bn_bwd_apply: bad arguments");
+                                  const float* gamma, const double* sums, double count, const double* count_dev, int N, int C,
+                                  int64_t HW, float* dz, float* dgamma, float* dbeta, dasac_stream_t stream) {
+  DASAC_REQUIRE(dy && z && mean && invstd && gamma && sums && dz && (count > 0 || count_dev), "bn_bwd_apply: bad arguments");
   const int64_t total = (int64_t)N * C * HW;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(bn_bwd_apply, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, z, mean, invstd, gamma, sums, count, C,
-                     (int)HW, dz, total);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(stream_grid(total, 256)), dim3(256), 0, s, dy, z, mean, invstd, gamma, sums, count,
+                     count_dev, C, (int)HW, dz, total);
   DASAC_CHECK_LAUNCH("bn_bwd_apply");
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(bn_bwd_params, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma, dbeta);
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void iou_counts(const float* __restrict__ logi
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
     const int64_t b = p / HW, r = p - b * HW;
     const int64_t y = gt[p];
-    if (y == ignore_index || y < 0 || y >= C) continue;
+    if (y == ignore_index) continue;        // utils/metrics.py:28-30: only ignore_index pixels are dropped
     const float* lp = logits + b * C * HW + r;
     float best = lp[0];
     int k = 0;
@@ -525,11 +530,11 @@ __global__ __launch_bounds__(256) void iou_counts(const float* __restrict__ logi
         k = c;
       }
     }
-    if (k == (int)y) {
+    if (y == k) {
       atomicAdd(&s[k], 1u);                 // tp
     } else {
-      atomicAdd(&s[64 + k], 1u);            // fp of the predicted class
-      atomicAdd(&s[128 + (int)y], 1u);      // fn of the true class
+      atomicAdd(&s[64 + k], 1u);            // fp of the predicted class (also when gt is no class at all, e.g. -1)
+      if (y >= 0 && y < C) atomicAdd(&s[128 + (int)y], 1u);      // fn of the true class
     }
   }
   __syncthreads();

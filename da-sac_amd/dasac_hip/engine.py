@@ -41,13 +41,20 @@ class ConvOp:
         # few output channels x many taps (ASPP): evaluate as dense 1x1 GEMMs over taps*Cp channels
         self.expanded = ops.ExpandedConv(self.spec) if (len(convs) > 1 and c0.out_channels <= 32 and c0.stride[0] == 1) else None
 
-    def params(self):
-        out = [c.weight for c in self.convs]
+    def owners(self):
+        """(module, attribute) of every parameter, in the order of params()."""
+        out = [(c, "weight") for c in self.convs]
         if self.has_bias:
-            out += [c.bias for c in self.convs]
+            out += [(c, "bias") for c in self.convs]
         if self.bn is not None:
-            out += [self.bn.weight, self.bn.bias]
+            out += [(self.bn, "weight"), (self.bn, "bias")]
         return out
+
+    def params(self):
+        return [getattr(m, a) for m, a in self.owners()]
+
+    def geometry(self):
+        return tuple((c.kernel_size, c.dilation, c.padding, c.stride, c.bias is not None) for c in self.convs)
 
 
 class PoolOp:
@@ -131,12 +138,15 @@ class Engine:
 
     def __init__(self, plan):
         self.plan = plan
-        self.params = []
+        self.params, self._owners, self._geometry = [], [], []
         for op in plan.ops:
             op.pidx = []
             for p in op.params():
                 op.pidx.append(len(self.params))
                 self.params.append(p)
+            if op.kind == "conv":
+                self._owners += op.owners()
+                self._geometry.append((op, op.geometry()))
         self.consumers = [0] * plan.n_slots
         self.producer = [None] * plan.n_slots
         for i, op in enumerate(plan.ops):
@@ -149,6 +159,13 @@ class Engine:
                 self.last_use[s] = i
         self.last_use[plan.output] = len(plan.ops)
         self._tables, self._packs, self._folds = {}, {}, {}
+
+    def stale(self):
+        """True when a module no longer holds the Parameter objects (or conv geometry) this engine captured:
+        `load_state_dict(assign=True)`, `m.weight = nn.Parameter(...)`, parametrizations, edited dilation/padding.
+        In-place updates (optimisers, copy_) are NOT stale -- the caches follow the version counters."""
+        return any(getattr(m, a) is not p for (m, a), p in zip(self._owners, self.params)) or \
+            any(op.geometry() != geo for op, geo in self._geometry)
 
     @staticmethod
     def _inputs(op):
@@ -269,7 +286,12 @@ class Engine:
             elif op.kind == "drop":
                 m = op.module
                 if m.training and m.p > 0:
-                    keep_mask = (torch.rand(xin.shape[:2], device=xin.device) >= m.p).to(torch.float32) / (1.0 - m.p)
+                    # ATen feature dropout (fcn.py:52,56): per (n, c) plane noise = bernoulli(1-p)/(1-p).  A test can pin
+                    # the draw by setting `module.keep_mask` ([B,C], already divided by 1-p) -- parity needs equal masks.
+                    keep_mask = getattr(m, "keep_mask", None)
+                    if keep_mask is None:
+                        keep_mask = (torch.rand(xin.shape[:2], device=xin.device) >= m.p).to(torch.float32) / (1.0 - m.p)
+                    assert tuple(keep_mask.shape) == tuple(xin.shape[:2]) and keep_mask.is_cuda
                     out = ops.scale_planes(xin, keep_mask)
                     if keep:
                         saved["aux"][i] = keep_mask
@@ -426,6 +448,9 @@ class _PlanFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if ctx.saved is None:
+            raise RuntimeError("dasac_hip engine: the activations of this forward were already consumed by a backward pass "
+                               "(retain_graph / a second backward through the same forward is not supported)")
         need = list(ctx.needs_input_grad[2:])
         grads = ctx.engine.backward(ctx.saved, grad_out, need)
         ctx.saved = None

@@ -51,10 +51,10 @@ PROTOTYPES = {
     "dasac_add": (_i, [_p, _p, _p, _l, _p]),
     "dasac_relu_mask": (_i, [_p, _p, _p, _l, _p]),
     "dasac_bn_stats": (_i, [_p, _i, _i, _l, _p, _p]),
-    "dasac_bn_train_finalize": (_i, [_p, C.c_double, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "dasac_bn_train_finalize": (_i, [_p, C.c_double, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
     "dasac_bn_apply": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p, _p]),
     "dasac_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p]),
-    "dasac_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, C.c_double, _i, _i, _l, _p, _p, _p, _p]),
+    "dasac_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, C.c_double, _p, _i, _i, _l, _p, _p, _p, _p]),
     "dasac_conv_pack_expanded": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_tap_gather": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     "dasac_tap_scatter": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),

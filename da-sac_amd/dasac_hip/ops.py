@@ -342,17 +342,22 @@ POOL_MODES = {"avg_pool": 0, "minentropy_pool": 1}
 
 
 def warp_pool(probs, theta, theta_inv, T, mode="avg_pool", tolerance=0.1, want_aligned=True):
-    """probs [N*T,C,H,W] -> (pooled [N,C,H,W], mask [N,1,H,W], aligned or None)."""
+    """probs [N*T,C,H,W] -> (pooled [N,C,H,W], mask [N,1,H,W], aligned or None).  theta None: the views are already
+    aligned and coverage-weighted, only the pooling runs (SAC._avg_pool / _minentropy_pool called on their own)."""
     lib = L.load()
     L.require_gpu(probs, theta, theta_inv)
-    probs, theta, theta_inv = _c(probs), _c(theta), _c(theta_inv)
+    probs = _c(probs)
+    if theta is None:
+        theta_inv, want_aligned = None, False
+    else:
+        theta, theta_inv = _c(theta), _c(theta_inv)
     NT, Cn, H, W = probs.shape
     assert NT % T == 0
     N = NT // T
     pooled = _f32((N, Cn, H, W), probs)
     mask = _f32((N, 1, H, W), probs)
     aligned = torch.empty_like(probs) if want_aligned else None
-    L.check(lib.dasac_warp_pool(probs.data_ptr(), theta.data_ptr(), theta_inv.data_ptr(), N, T, Cn, H, W, POOL_MODES[mode],
+    L.check(lib.dasac_warp_pool(probs.data_ptr(), L.ptr(theta), L.ptr(theta_inv), N, T, Cn, H, W, POOL_MODES[mode],
                                 float(tolerance), L.ptr(aligned), pooled.data_ptr(), mask.data_ptr(), L.stream_ptr()),
             "dasac_warp_pool")
     return pooled, mask, aligned
@@ -382,6 +387,39 @@ def class_state(running_conf, class_sums, B, HW, beta, stat_momentum, update, fo
                                   float(stat_momentum), int(bool(update)), float(focal_p), L.ptr(disc), L.ptr(focal),
                                   L.stream_ptr()), "dasac_class_state")
     return disc, focal
+
+
+class HostClassVectors:
+    """disc = 1 - exp(-chi/beta) (sac.py:151-152) and focal = (1 - clamp(chi, 0))**p (sac.py:120,135) computed by the
+    SAME CPU ATen kernels the reference runs (true division by the python scalar, Sleef exp/pow) so that the per-class
+    thresholds -- and with them the integer label map -- are bit-equal to the CPU reference's on equal probabilities;
+    the device's expf/powf differ from Sleef's in the last bit on some inputs.
+
+    Cost: 19 floats D2H + 2x19 H2D per target step.  `start()` queues the copy of chi into pinned memory right
+    after the kernel that updates it; `finish()` (called after the warp/pool kernels were queued, so the GPU has
+    work while the host waits) runs the two formulas on the host and uploads them without blocking."""
+
+    def __init__(self, running_conf):
+        self.host = torch.empty(running_conf.shape, dtype=torch.float32).pin_memory()
+        self.host.copy_(running_conf.detach(), non_blocking=True)
+        self.done = torch.cuda.Event()
+        self.done.record()
+        self.device = running_conf.device
+
+    def finish(self, beta, focal_p, want_disc=True):
+        self.done.synchronize()
+        chi = self.host
+        vecs = torch.empty((2,) + tuple(chi.shape), dtype=torch.float32).pin_memory()
+        vecs[0] = 1 - torch.exp(-chi / beta) if want_disc else 1.0
+        vecs[1] = (1 - chi.clamp(0.)) ** focal_p
+        dev = vecs.to(self.device, non_blocking=True)
+        return (dev[0] if want_disc else None), dev[1]
+
+
+def class_vectors(running_conf, beta, focal_p, want_disc=True):
+    """One-shot form of HostClassVectors (blocks until the stream reaches this point)."""
+    L.require_gpu(running_conf)
+    return HostClassVectors(running_conf).finish(beta, focal_p, want_disc)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -530,28 +568,29 @@ def _world():
 
 
 def _allreduce_sums(sums, count):
-    """SyncBN: one all-reduce of the raw sums (+ element count) over RCCL; identity on one rank."""
+    """SyncBN: one all-reduce of the raw sums + the element count over RCCL (deeplabv2.py:15); identity on one rank.
+    Returns (sums, host count or 0.0, device count or None) -- with several ranks the count stays on the device."""
     if _world() == 1:
-        return sums, float(count)
+        return sums, float(count), None
     import torch.distributed as dist
     packed = torch.cat([sums, torch.tensor([float(count)], dtype=torch.float64, device=sums.device)])
     dist.all_reduce(packed)
-    return packed[:-1].contiguous(), float(packed[-1])
+    return packed[:-1], 0.0, packed[-1:]
 
 
 def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
-    """y = relu?(BN_batch(z) (+res)); returns (y, (mean, invstd, count)).  Updates bn.running_* like ATen."""
+    """y = relu?(BN_batch(z) (+res)); returns (y, (mean, invstd, count, count_dev)).  Updates bn.running_* like ATen."""
     lib = L.load()
     L.require_gpu(z, res)
     N, Cn = z.shape[0], z.shape[1]
     HW = z[0, 0].numel()
     sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
     L.check(lib.dasac_bn_stats(z.data_ptr(), N, Cn, HW, sums.data_ptr(), L.stream_ptr()), "dasac_bn_stats")
-    sums, count = _allreduce_sums(sums, N * HW)
+    sums, count, count_dev = _allreduce_sums(sums, N * HW)
     scale, shift, mean, invstd = (_f32((Cn,), z) for _ in range(4))
     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
     upd = update_running and bn.track_running_stats
-    L.check(lib.dasac_bn_train_finalize(sums.data_ptr(), count, bn.weight.data_ptr(), bn.bias.data_ptr(),
+    L.check(lib.dasac_bn_train_finalize(sums.data_ptr(), count, L.ptr(count_dev), bn.weight.data_ptr(), bn.bias.data_ptr(),
                                         bn.running_mean.data_ptr() if upd else None, bn.running_var.data_ptr() if upd else None,
                                         float(mom), float(bn.eps), Cn, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                         invstd.data_ptr(), L.stream_ptr()), "dasac_bn_train_finalize")
@@ -561,14 +600,14 @@ def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
     y = torch.empty_like(z)
     L.check(lib.dasac_bn_apply(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), int(relu), N, Cn, HW, y.data_ptr(),
                                L.stream_ptr()), "dasac_bn_apply")
-    return y, (mean, invstd, count)
+    return y, (mean, invstd, count, count_dev)
 
 
 def bn_train_backward(dy, z, stats, gamma, want_params=True):
     """dy: gradient w.r.t. the BN output (ReLU mask already applied).  Returns (dz, dgamma, dbeta)."""
     lib = L.load()
     L.require_gpu(dy, z)
-    mean, invstd, count = stats
+    mean, invstd, count, count_dev = stats
     N, Cn = z.shape[0], z.shape[1]
     HW = z[0, 0].numel()
     dy = _c(dy)
@@ -584,7 +623,8 @@ def bn_train_backward(dy, z, stats, gamma, want_params=True):
     dg = _f32((Cn,), z) if want_params else None
     db = _f32((Cn,), z) if want_params else None
     L.check(lib.dasac_bn_bwd_apply(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                   sums.data_ptr(), float(count), N, Cn, HW, dz.data_ptr(), None, None, L.stream_ptr()),
+                                   sums.data_ptr(), float(count), L.ptr(count_dev), N, Cn, HW, dz.data_ptr(), None, None,
+                                   L.stream_ptr()),
             "dasac_bn_bwd_apply")
     if want_params:     # parameter gradients are LOCAL sums (DDP averages them across ranks afterwards)
         dg.copy_(local[Cn:].to(torch.float32))

@@ -17,14 +17,68 @@ def make_optimizer(net, cfg_model, fused=True):
     return torch.optim.SGD(groups, momentum=cfg_model.MOMENTUM, nesterov=nesterov)
 
 
+def _dist_state(rank, world):
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    if world is None:
+        world = dist.get_world_size() if on else 1
+    if rank is None:
+        rank = dist.get_rank() if on else 0
+    return rank, world
+
+
+def prep_batch(tensor, num_groups, group_size, rank=None, world=None, device=None, exchange="all_gather"):
+    """Rank-local slice of one loaded target tensor [B, L, ...] (train.py:157-209).
+
+    Every rank's loader delivers whole groups of L views.  With N*L/world >= L the groups stay where they were
+    loaded: the result is just [B*L, ...].  Otherwise a group is spread over L/per consecutive ranks
+    (per = N*L/world views each): rank r keeps views [f % L, f % L + per) of the first group loaded by rank
+    f // L, f = r*per (the groups loaded by the other ranks are dropped, as in the reference).
+    exchange="all_gather" moves the tensors exactly like train.py:194-195; "p2p" sends each rank only the `per`
+    views it keeps (same result, 1/world of the bytes -- xGMI links are point-to-point anyway)."""
+    import torch.distributed as dist
+    rank, world = _dist_state(rank, world)
+    assert (num_groups * group_size) % world == 0, "Batch size does not fit world size"
+    per = num_groups * group_size // world
+    if device is not None:
+        tensor = tensor.to(device, non_blocking=True)
+    if per >= group_size:
+        return tensor.flatten(0, 1)
+    assert tensor.size(1) == group_size, "Loaded sequence is incorrect {} vs. {}".format(tensor.size(1), group_size)
+    first = rank * per
+    owner, lo = first // group_size, first % group_size
+    tensor = tensor.contiguous()
+    if exchange == "all_gather":
+        parts = [torch.empty_like(tensor) for _ in range(world)]
+        dist.all_gather(parts, tensor)
+        return parts[owner].flatten(0, 1)[lo:lo + per]
+    assert exchange == "p2p", exchange
+    flat = tensor.flatten(0, 1)
+    mine = flat[lo:lo + per].clone() if owner == rank else torch.empty_like(flat[:per])
+    work = []
+    for dst in range(world):                    # what this rank owes the ranks whose slice lives here
+        if dst != rank and (dst * per) // group_size == rank:
+            d_lo = (dst * per) % group_size
+            work.append(dist.P2POp(dist.isend, flat[d_lo:d_lo + per].contiguous(), dst))
+    if owner != rank:
+        work.append(dist.P2POp(dist.irecv, mine, owner))
+    if work:
+        for req in dist.batch_isend_irecv(work):
+            req.wait()
+    return mine
+
+
 def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_teacher, lr_target, target_only=False):
     """source fwd -> zero_grad -> source bwd (gradients kept) -> target fwd (teacher EMA first when asked)
     -> (LR_TARGET * self_ce) bwd -> one optimiser step.  Returns (source losses, target losses, net_outs)
-    with the losses still on the device (no host sync here)."""
-    images, masks = src_batch
-    losses_src, _ = net(images, masks)
-    optim.zero_grad()
-    losses_src["loss_ce"].mean().backward()
+    with the losses still on the device (no host sync here).  TRAIN.TARGET_ONLY skips the source pass altogether
+    (train.py:274-276) and clears the gradients before the target backward (train.py:226-227)."""
+    losses_src = {}
+    if not target_only:
+        images, masks = src_batch
+        losses_src, _ = net(images, masks)
+        optim.zero_grad()
+        losses_src["loss_ce"].mean().backward()
     frames1, frames_gt, frames2, affine, affine_inv = tgt_batch
     losses_tgt, outs = net(frames1, frames_gt, frames2, affine, affine_inv, use_teacher=True,
                            update_teacher=update_teacher, T=group_size)
@@ -33,6 +87,21 @@ def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_tea
     (lr_target * losses_tgt["self_ce"].mean()).backward()
     optim.step()
     return losses_src, losses_tgt, outs
+
+
+def reduce_losses(losses, world=None):
+    """train.py:243-246: every logged loss is summed over ranks and divided by the world size (one collective for the
+    whole dict instead of one per key); returns python floats (the only host sync of a step)."""
+    import torch.distributed as dist
+    _, world = _dist_state(None, world)
+    keys = sorted(losses)
+    if not keys:
+        return {}
+    packed = torch.cat([losses[k].detach().reshape(-1)[:1] for k in keys])
+    if world > 1:
+        dist.all_reduce(packed)
+        packed = packed / world
+    return dict(zip(keys, packed.tolist()))
 
 
 def baseline_train_iteration(net, optim, src_batch, tgt_images):

@@ -106,7 +106,7 @@ class BaseNet(nn.Module):
         return all(not m.training for m in self.modules() if isinstance(m, BaseNet._batchnorm))
 
     def _logits(self, im):
-        if self._engine is None:
+        if self._engine is None or self._engine.stale():      # parameter objects replaced -> re-capture the plan
             self._engine = E.Engine(self._plan())
         return E.run_plan(self._engine, im)
 

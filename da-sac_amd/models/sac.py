@@ -51,6 +51,7 @@ class SAC(SAC_Baseline):
             p.requires_grad = False
         self.register_buffer("slow_init", torch.Tensor([False]))
         self._ema_plan = None
+        self._class_vectors = None
 
     def _get_op(self, name):
         op_name = "_{}".format(name)
@@ -88,13 +89,12 @@ class SAC(SAC_Baseline):
                         self.cfg.FOCAL_P, want_disc=False, want_focal=False)
 
     def _threshold_discount(self):
-        disc, _ = ops.class_state(self.running_conf, None, 1, 1, self.cfg.THRESHOLD_BETA, self.cfg.STAT_MOMENTUM, False,
-                                  self.cfg.FOCAL_P, want_focal=False)
+        """1 - exp(-chi/beta), evaluated by the CPU ATen kernels the reference uses (bit-equal thresholds)."""
+        disc, _ = ops.class_vectors(self.running_conf, self.cfg.THRESHOLD_BETA, self.cfg.FOCAL_P)
         return disc
 
     def _focal_weight(self, p):
-        _, fw = ops.class_state(self.running_conf, None, 1, 1, self.cfg.THRESHOLD_BETA, self.cfg.STAT_MOMENTUM, False, p,
-                                want_disc=False)
+        _, fw = ops.class_vectors(self.running_conf, self.cfg.THRESHOLD_BETA, p, want_disc=False)
         return fw
 
     # ------------------------------------------------------------------ losses (sac.py:119-149)
@@ -130,10 +130,30 @@ class SAC(SAC_Baseline):
         first = stride * (self.rank * B // T)
         return torch.cat(parts[first:first + stride], 0)
 
+    @torch.no_grad()
     def _avg_pool(self, probs, T, tolerance=0.1):
-        raise RuntimeError("pooling runs fused inside _refine (dasac_warp_pool); not callable on its own")
+        """sac.py:238-269 on views that are already aligned (and coverage-weighted): gather the group's missing
+        views, sum over the T views, normalise over classes; the result is repeated for the T0 = min(T, B) views
+        this rank holds.  (`_refine` runs the same arithmetic fused with the warps.)"""
+        T0 = min(T, probs.size(0))
+        probs = self._gather(probs, T)
+        pooled, mask, _ = ops.warp_pool(probs, None, None, T, "avg_pool", tolerance)
+        N, C, H, W = pooled.shape
+        return (pooled[:, None].expand(N, T0, C, H, W).flatten(0, 1).contiguous(),
+                mask[:, None].expand(N, T0, 1, H, W).flatten(0, 1).contiguous())
 
-    _minentropy_pool = _avg_pool
+    @torch.no_grad()
+    def _minentropy_pool(self, probs, T, tolerance=0.1):
+        """sac.py:218-236: every view takes the probs of its group's lowest-entropy view (written back into `probs`
+        like the reference does, :234).  No cross-rank gather exists for this pooling: all T views must be local."""
+        BT, C, H, W = probs.size()
+        if BT % T:
+            raise RuntimeError("minentropy_pool needs whole groups of T={} views on a rank, got {} (the reference's "
+                               "view(-1,T,1,H,W) at sac.py:222 fails the same way)".format(T, BT))
+        pooled, mask, _ = ops.warp_pool(probs, None, None, T, "minentropy_pool", tolerance)
+        N = BT // T
+        probs.view(N, T, C, H, W).copy_(pooled[:, None].expand(N, T, C, H, W))
+        return probs, mask[:, None].expand(N, T, 1, H, W).flatten(0, 1).contiguous()
 
     @torch.no_grad()
     def _refine(self, frames, pred_logits, T, affine, affine_inv, ignore_mask, pool=True, debug=True):
@@ -145,14 +165,19 @@ class SAC(SAC_Baseline):
         if self.training:
             ops.class_state(self.running_conf, sums, B, h * w, self.cfg.THRESHOLD_BETA, self.cfg.STAT_MOMENTUM, True,
                             self.cfg.FOCAL_P, want_disc=False, want_focal=False)
+        self._class_vectors = ops.HostClassVectors(self.running_conf)      # chi is final for this step: start its D2H
         diags = {}
         if not pool:
             return probs, diags
         T_local = min(T, B)            # views of a group held by this rank (sac.py:244)
         affine, affine_inv = affine.contiguous(), affine_inv.contiguous()
         if T_local < T:
-            # views sharded across ranks: every rank needs all T warped views of its group.  The warp is
-            # linear, so gather the un-warped probs and thetas of the group instead (sac.py:246).
+            # views sharded across ranks: every rank needs all T aligned views of its group (sac.py:246).  The warp
+            # is per view, so gathering the un-warped probs and their thetas and warping here yields the same bits
+            # as gathering the other ranks' warped views, and keeps warp + pool one fused pass.
+            if self.cfg.CONF_POOL != "avg_pool":
+                raise RuntimeError("{} has no cross-rank gather: a rank must hold whole groups of T={} views, got {} "
+                                   "(sac.py:222 fails in the reference)".format(self.cfg.CONF_POOL, T, B))
             probs_g, aff_g, inv_g = self._gather(probs, T), self._gather(affine, T), self._gather(affine_inv, T)
             pooled, mask, aligned_g = ops.warp_pool(probs_g, aff_g, inv_g, T, self.cfg.CONF_POOL, want_aligned=True)
             lo = (self.rank * B) % T
@@ -185,10 +210,11 @@ class SAC(SAC_Baseline):
             with torch.no_grad():
                 slow_logits, slow_logits_up = self.slow_net(x2)
                 probs_teacher, diags = self._refine(x2, slow_logits, T, affine, affine_inv, ignore_mask, pool=self.cfg.CONF_POOL_ON)
-                disc = self._threshold_discount() if self.cfg.CONF_DISCOUNT else None
+                # thresholds / focal weights from chi by the reference's own CPU arithmetic (bit-equal label maps);
+                # the 19-float round trip was started inside _refine and lands while the warps run
+                disc, fw = self._class_vectors.finish(self.cfg.THRESHOLD_BETA, self.cfg.FOCAL_P, self.cfg.CONF_DISCOUNT)
                 pseudo_labels, teacher_conf, _ = ops.pseudo_labels(probs_teacher, ignore_mask, self.cfg.RUN_CONF_UPPER,
                                                                    self.cfg.RUN_CONF_LOWER, disc)
-            fw = self._focal_weight(self.cfg.FOCAL_P)
             conf = teacher_conf if self.cfg.LOSS == "focal_ce_conf" else None
             losses["self_ce"] = E.focal_ce(net_outs["logits_up"], pseudo_labels, fw, conf).view(1)
             net_outs["teacher_init"] = slow_logits_up

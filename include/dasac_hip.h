@@ -162,7 +162,8 @@ int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, int OH, int 
  * dasac_warp_affine       grid_sample(x, affine_grid(theta), bilinear, zeros, align_corners=False)
  * dasac_warp_pool         sac.py:289-305 with _avg_pool (mode 0, :238-269) or _minentropy_pool
  *     (mode 1, :218-236): probs [N*T,C,H,W] -> pooled [N,C,H,W], mask [N,H,W]; `aligned`
- *     (optional) = teacher_aligned diagnostic [N*T,C,H,W].
+ *     (optional) = teacher_aligned diagnostic [N*T,C,H,W].  theta == theta_inv == NULL: `probs` are
+ *     views that are already aligned and coverage-weighted (the pooling functions on their own).
  * dasac_warp_back         sac.py:309-311: refined[b] = warp(pooled[b/views_per_group]) * warp(mask)
  * dasac_class_state       sac.py:104-117 running prior update (if update) and the derived
  *     vectors disc = 1-exp(-chi/beta) (:152), focal = (1-max(chi,0))^p (:120); any may be NULL.
@@ -245,10 +246,12 @@ int dasac_relu_mask(const float* dy, const float* y, float* out, int64_t n, dasa
  *           the unbiased var; running_* may be NULL) -> dasac_bn_apply (y = relu?(z*scale+shift(+res))).
  * backward: dasac_bn_bwd_reduce (sums = sum dy, sum dy*xhat) -> [all-reduce] -> dasac_bn_bwd_apply
  *           (dz = gamma*invstd*(dy - sum_dy/n - xhat*sum_dy_xhat/n); dgamma, dbeta optional).
+ * `count` = elements per channel over all ranks; `count_dev` (device double, may be NULL) overrides it so
+ * that an all-reduced count never has to visit the host.
  */
 int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, dasac_stream_t stream);
-int dasac_bn_train_finalize(const double* sums, double count, const float* gamma, const float* beta,
-                            float* running_mean, float* running_var, float momentum, float eps, int C,
+int dasac_bn_train_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum, float eps, int C,
                             float* scale, float* shift, float* mean, float* invstd,
                             dasac_stream_t stream);
 int dasac_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu,
@@ -256,8 +259,8 @@ int dasac_bn_apply(const float* z, const float* scale, const float* shift, const
 int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd,
                         int N, int C, int64_t HW, double* sums, dasac_stream_t stream);
 int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const float* invstd,
-                       const float* gamma, const double* sums, double count, int N, int C, int64_t HW,
-                       float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);
+                       const float* gamma, const double* sums, double count, const double* count_dev, int N, int C,
+                       int64_t HW, float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);
 
 /* Validation counts (utils/metrics.py:9-53, train.py:339-469): counts[0:C] += tp, counts[C:2C] += fp,
  * counts[2C:3C] += fn of argmax_c logits vs gt (pixels with gt == ignore_index skipped); the caller

@@ -191,11 +191,16 @@ def minentropy_pool_views(aligned, T, tolerance=0.1):
 
 
 def refine(frames, teacher_logits, T, affine, affine_inv, ignore_mask, running_conf, *,
-           beta, stat_momentum, training=True, pool=True, pool_kind="avg_pool"):
+           beta, stat_momentum, training=True, pool=True, pool_kind="avg_pool", gather=None):
     """models/sac.py:271-313.  Returns (refined probs, new running_conf, diags).
 
     Note the reference's frame mix (quirk 4): the coverage of the *inverse* warp (view
     frame) multiplies the probs already warped into the *reference* frame (:299-305).
+
+    `gather(tensor, T)`: the cross-rank `_gather` of :198-216 when a rank holds B < T views of
+    a group (only `_avg_pool` calls it, :246; the pooled result is expanded to T0 = min(T, B)
+    views, :244,264-265).  `_minentropy_pool` has no gather: with B < T its `view(-1,T,...)`
+    (:222) raises, and so does this restatement.
     """
     B, _, H, W = frames.shape
     up = upsample_bilinear_ac(teacher_logits, H, W)
@@ -212,8 +217,13 @@ def refine(frames, teacher_logits, T, affine, affine_inv, ignore_mask, running_c
     diags["frames_aligned"] = warp_affine(frames, affine)
     cover = warp_coverage(affine_inv, H, W)
     if pool_kind == "avg_pool":
-        pooled, mask = avg_pool_views(aligned * cover, T)
+        views = aligned * cover
+        if gather is not None:
+            views = gather(views, T)
+        pooled, mask = avg_pool_views(views, T, min(T, B))
     elif pool_kind == "minentropy_pool":
+        if B % T:
+            raise RuntimeError("shape '[-1, {}, 1, {}, {}]' is invalid for input of size {}".format(T, H, W, B * H * W))
         pooled, mask = minentropy_pool_views(aligned * cover, T)
     else:
         raise AssertionError("Pooling OP _{} not found".format(pool_kind))

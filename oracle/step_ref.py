@@ -21,7 +21,8 @@ DEFAULT_CFG = dict(                      # core/config.py:130-159 + deeplabv2_re
 class SacOracle:
     """Student / momentum-teacher pair over flat state dicts (reference checkpoint keys)."""
 
-    def __init__(self, student_sd, cfg=None, num_classes=19, net_kwargs=None):
+    def __init__(self, student_sd, cfg=None, num_classes=19, net_kwargs=None, gather=None):
+        self.gather = gather                                  # cross-rank view gather (sac.py:198-216) or None
         self.cfg = dict(DEFAULT_CFG)
         self.cfg.update(cfg or {})
         self.arch = self.cfg["ARCH"].lower()
@@ -72,7 +73,7 @@ class SacOracle:
                 refined, chi, diags = H.refine(
                     x2, slow_logits, T, affine, affine_inv, ignore_mask, self.running_conf,
                     beta=c["THRESHOLD_BETA"], stat_momentum=c["STAT_MOMENTUM"], training=self.training,
-                    pool=c["CONF_POOL_ON"], pool_kind=c["CONF_POOL"])
+                    pool=c["CONF_POOL_ON"], pool_kind=c["CONF_POOL"], gather=self.gather)
                 self.running_conf.copy_(chi)
                 disc = H.threshold_discount(self.running_conf, c["THRESHOLD_BETA"]) if c["CONF_DISCOUNT"] else None
                 labels, conf, _ = H.pseudo_labels(refined, ignore_mask, c["RUN_CONF_UPPER"], c["RUN_CONF_LOWER"], disc)
@@ -183,3 +184,102 @@ def gather_index(world, rank, B, T):
         return None
     lo = stride * (rank * B // T)
     return lo, lo + stride
+
+
+# --------------------------------------------------------------------------------------------------
+# several ranks in one process: what DistributedDataParallel + the two hand-rolled all_gathers do
+# (train.py:104,157-209; models/sac.py:198-216), with threads standing in for ranks
+# --------------------------------------------------------------------------------------------------
+class ThreadWorld:
+    """`world` oracle ranks as threads; every collective is a barrier around a shared slot list."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._slots = [None] * world
+        self._bar = threading.Barrier(world)
+
+    def all_gather(self, rank, item):
+        self._slots[rank] = item
+        self._bar.wait()
+        out = list(self._slots)
+        self._bar.wait()
+        return out
+
+    def gather_views(self, rank):
+        """models/sac.py:198-216 for this rank."""
+        def fn(tensor, T):
+            idx = gather_index(self.world, rank, tensor.size(0), T)
+            if idx is None:
+                return tensor
+            parts = self.all_gather(rank, tensor)
+            return torch.cat(parts[idx[0]:idx[1]], 0)
+        return fn
+
+    def prep_batch(self, rank, loaded, N_groups, L):
+        """train.py:157-209: `loaded` [B,L,...] is what this rank's loader delivered."""
+        idx = view_slice_index(self.world, rank, N_groups, L)
+        if idx is None:
+            return loaded.flatten(0, 1)
+        assert loaded.size(1) == L
+        parts = self.all_gather(rank, loaded)
+        return parts[idx[0]].flatten(0, 1)[idx[1]:idx[2]]
+
+    def average_grads(self, rank, model):
+        """DDP's bucketed all-reduce(SUM)/world after a backward pass (train.py:104)."""
+        mine = {k: v.grad for k, v in model.student.items() if v.requires_grad and v.grad is not None}
+        parts = self.all_gather(rank, mine)
+        for k in mine:
+            model.student[k].grad = sum(p[k] for p in parts) / self.world
+
+    def broadcast_buffers(self, rank, model):
+        """DDP(broadcast_buffers=True): before every forward all buffers take rank 0's values (quirk 5)."""
+        src = self.all_gather(rank, model)[0]
+        if rank != 0:
+            model.running_conf.copy_(src.running_conf)
+            model.slow_init.copy_(src.slow_init)
+            for sd_mine, sd_src in ((model.student, src.student), (model.teacher, src.teacher)):
+                for k, v in sd_src.items():
+                    if k.split(".")[-1] in ("running_mean", "running_var", "num_batches_tracked"):
+                        sd_mine[k].copy_(v.detach())
+        self._bar.wait()
+
+    def run(self, fn):
+        """Runs fn(rank) on every rank; returns the results in rank order (first exception re-raised)."""
+        import threading
+        out, err = [None] * self.world, []
+
+        def body(r):
+            try:
+                out[r] = fn(r)
+            except BaseException as e:       # noqa: a failing rank must not leave the others at a barrier
+                err.append(e)
+                self._bar.abort()
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        real = [e for e in err if not isinstance(e, threading.BrokenBarrierError)]
+        if err:
+            raise (real or err)[0]
+        return out
+
+
+def sharded_sac_iteration(tw, rank, model, optim, src_batch, loaded_tgt, N_groups, L, update_teacher):
+    """train.py:266-298 on rank `rank` of a ThreadWorld: DDP buffer broadcast before each forward, gradient
+    averaging after each backward, `_prep_batch` on the five loaded target tensors."""
+    xs, ys = src_batch
+    tw.broadcast_buffers(rank, model)
+    losses_src, _ = model.forward(xs, ys)
+    optim.zero_grad()
+    losses_src["loss_ce"].mean().backward()
+    tw.average_grads(rank, model)
+    f1, gt, f2, aff, aff_inv = (tw.prep_batch(rank, t, N_groups, L) for t in loaded_tgt)
+    tw.broadcast_buffers(rank, model)
+    losses_tgt, outs = model.forward(f1, gt.clone(), f2, aff, aff_inv, use_teacher=True, update_teacher=update_teacher, T=L)
+    (model.cfg["LR_TARGET"] * losses_tgt["self_ce"].mean()).backward()
+    tw.average_grads(rank, model)
+    optim.step()
+    return ({k: float(v.detach().mean()) for k, v in losses_src.items()},
+            {k: float(v.detach().mean()) for k, v in losses_tgt.items()}, outs)

@@ -241,6 +241,7 @@ def g2_resnet():
         for k in GRAD_PROBE_KEYS:
             out[tag + "_g_" + k] = _sampled(named[k].grad, 64)
             out[tag + "_gn_" + k] = named[k].grad.norm()
+            out[tag + "_gm_" + k] = named[k].grad.abs().max()
         if not freeze:
             st = net.state_dict()
             out["train_rm_bn1"] = st["model.bn1.running_mean"]
@@ -342,9 +343,84 @@ def keys_fixture():
          group_lr=np.array([g["lr"] for g in groups]), group_wd=np.array([g["weight_decay"] for g in groups]), **gk)
 
 
+# ------------------------------------------------------------------------------------------------
+# G11: rank -> view index tables of Trainer._prep_batch (train.py:157-209) and SAC._gather
+# (models/sac.py:198-216), captured by running the reference's own (unbound) methods in `world`
+# gloo processes on CPU.  train.py imports at module level a few packages this image lacks
+# (setproctitle, tensorboard, torchvision.utils); none of them is touched by the two methods, so
+# empty module objects of those names are registered first.
+# ------------------------------------------------------------------------------------------------
+G11_CASES = [(1, 2, 4), (2, 1, 2), (2, 2, 4), (4, 2, 4), (4, 1, 4), (8, 2, 4), (8, 4, 4), (8, 16, 4)]   # (world, N, L)
+
+
+class _StaysOnCpu(torch.Tensor):
+    """`tensor.cuda(gpu)` (train.py:183) is a no-op in this GPU-less container."""
+
+    def cuda(self, *a, **k):
+        return self
+
+
+def _g11_rank(rank, world, port, cases, q):
+    import types
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for name in ("setproctitle", "torch.utils.tensorboard", "torchvision.utils"):
+        m = types.ModuleType(name)
+        m.SummaryWriter = object
+        sys.modules.setdefault(name, m)
+    import torchvision
+    torchvision.utils = sys.modules["torchvision.utils"]
+    import train as ref_train                      # the reference's train.py
+    from models.sac import SAC as RefSAC
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for (w, N, L) in cases:
+        ref_cfg.TRAIN.NUM_GROUPS, ref_cfg.TRAIN.GROUP_SIZE = N, L
+        shim = types.SimpleNamespace(cfg=ref_cfg, world_size=world, gpu=rank, rank=rank)
+        Bl = max(1, N // world)                   # datasets/__init__.py:66 loader batch of target images
+        b = torch.arange(Bl).view(Bl, 1, 1)
+        t = torch.arange(L).view(1, L, 1)
+        loaded = (rank * 1000 + b * 10 + t).expand(Bl, L, 2).contiguous().float().as_subclass(_StaysOnCpu)
+        got = ref_train.Trainer._prep_batch(shim, loaded)
+        got = torch.Tensor(got)[:, 0].long() if got.dim() == 2 else got.as_subclass(torch.Tensor)[..., 0].long()
+        out["prep_w%d_N%d_L%d" % (w, N, L)] = got.numpy()
+        B = got.shape[0]
+        mine = (rank * 100 + torch.arange(B)).float().view(B, 1)
+        gathered = RefSAC._gather(shim, mine, L)
+        out["gather_w%d_N%d_L%d" % (w, N, L)] = gathered[:, 0].long().numpy()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def g11_index_tables():
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    rec = {}
+    for world in sorted({c[0] for c in G11_CASES}):
+        cases = [c for c in G11_CASES if c[0] == world]
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_g11_rank, args=(r, world, port, cases, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=600) for _ in procs)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        for key in res[0]:
+            rec[key] = np.stack([res[r][key] for r in range(world)])       # [world, ...]
+    rec["cases"] = np.array(G11_CASES)
+    save("g11_index_tables", **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys"]
+    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11"]
     table = dict(g3=g3_bilinear, g4=g4_refine, g5=g5_pseudo_labels, g6=g6_losses, g7=g7_state_sequences,
-                 g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture)
+                 g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture, g11=g11_index_tables)
     for w in which:
         table[w]()

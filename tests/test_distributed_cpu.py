@@ -66,3 +66,83 @@ def test_rank_slicing_tables_match_reference_comments():
     assert [view_slice_index(8, r, 2, 4) for r in range(8)] == [(r // 4, r % 4, r % 4 + 1) for r in range(8)]
     with pytest.raises(AssertionError):
         view_slice_index(3, 0, 2, 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# G11: the reference's own Trainer._prep_batch / SAC._gather run unbound in `world` gloo processes
+# (tests/golden/make_goldens.py: g11_index_tables) -> which loaded (rank, image, view) every rank ends up with
+# ---------------------------------------------------------------------------------------------------------------
+def _loaded(rank, world, N, L):
+    Bl = max(1, N // world)                                   # datasets/__init__.py:66
+    b, t = torch.arange(Bl).view(Bl, 1, 1), torch.arange(L).view(1, L, 1)
+    return (rank * 1000 + b * 10 + t).expand(Bl, L, 2).contiguous().float()
+
+
+def test_oracle_rank_tables_match_reference_golden_g11(golden):
+    from oracle.step_ref import ThreadWorld
+    g = golden("g11_index_tables")
+    for world, N, L in g["cases"].tolist():
+        tw = ThreadWorld(world)
+
+        def rank_fn(r):
+            got = tw.prep_batch(r, _loaded(r, world, N, L), N, L)
+            mine = (r * 100 + torch.arange(got.shape[0])).float().view(-1, 1)
+            return got[:, 0].long(), tw.gather_views(r)(mine, L)[:, 0].long()
+        res = tw.run(rank_fn)
+        tag = "_w%d_N%d_L%d" % (world, N, L)
+        assert torch.equal(torch.stack([r[0] for r in res]), torch.from_numpy(g["prep" + tag])), tag
+        assert torch.equal(torch.stack([r[1] for r in res]), torch.from_numpy(g["gather" + tag])), tag
+
+
+def _g11_worker(rank, world, port, cases, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "da-sac_amd"))
+    import driver
+    import models
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL=""))
+    net = models.get_model(cfg, rank, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    out = {}
+    for (w, N, L) in cases:
+        for how in ("all_gather", "p2p"):
+            got = driver.prep_batch(_loaded(rank, world, N, L), N, L, exchange=how)
+            out[("prep", how, w, N, L)] = got[:, 0].long()
+        mine = (rank * 100 + torch.arange(got.shape[0])).float().view(-1, 1)
+        out[("gather", w, N, L)] = net._gather(mine, L)[:, 0].long()
+    q.put((rank, {k: v.tolist() for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_product_prep_batch_and_gather_match_reference_golden_g11(golden, world):
+    g = golden("g11_index_tables")
+    cases = [c for c in g["cases"].tolist() if c[0] == world]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_g11_worker, args=(r, world, port, cases, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for w, N, L in cases:
+        tag = "_w%d_N%d_L%d" % (w, N, L)
+        for how in ("all_gather", "p2p"):
+            assert [res[r][("prep", how, w, N, L)] for r in range(world)] == g["prep" + tag].tolist(), (tag, how)
+        assert [res[r][("gather", w, N, L)] for r in range(world)] == g["gather" + tag].tolist(), tag
+
+
+def test_prep_batch_single_process_and_bad_world():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "da-sac_amd"))
+    import driver
+    t = torch.arange(2 * 4 * 3).view(2, 4, 3)
+    assert torch.equal(driver.prep_batch(t, 2, 4, rank=0, world=1), t.flatten(0, 1))     # train.py:186-187
+    with pytest.raises(AssertionError, match="Batch size does not fit world size"):
+        driver.prep_batch(t, 2, 4, rank=0, world=3)

@@ -96,3 +96,83 @@ def test_eval_forward_after_train_mode_steps_uses_the_new_running_stats():
         e2, _ = fresh(x)
     assert rel_err(e1, e0) > 1e-3
     assert rel_err(e1, e2) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SyncBatchNorm across ranks (deeplabv2.py:15; cfg-2 on more than one GPU): two ranks share the box's GPU over gloo.
+# Batch statistics are global, so the two ranks together must reproduce ONE process that sees the concatenated
+# batch: per-rank losses = the CE of each half, DDP-averaged gradients = gradient of the CE over all four crops,
+# running statistics = those of the four crops (count = global count in the unbiased variance).
+# ---------------------------------------------------------------------------------------------------------------
+_SYNC_PROBE = ("model.conv1.weight", "model.bn1.weight", "model.layer2.1.bn2.bias", "model.layer3.5.conv2.weight",
+               "model.layer5.conv2d_list.1.bias")
+_SYNC_STATS = ("model.bn1.running_mean", "model.layer2.1.bn3.running_var", "model.layer4.2.bn1.running_mean")
+
+
+def _sync_data(rank):
+    g = torch.Generator().manual_seed(40 + rank)
+    return (torch.randn(2, 3, 33, 41, generator=g), torch.randint(0, 19, (2, 33, 41), generator=g),
+            torch.randn(2, 3, 33, 41, generator=g))
+
+
+def _syncbn_rank(rank, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p_ in (root, os.path.join(root, "da-sac_amd"), os.path.join(root, "tests")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    import models
+    import driver
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False, BASELINE=True))
+    net = models.get_model(cfg, rank, num_classes=19, criterion=CRIT)
+    net.backbone.load_state_dict(N.resnet101_state(seed=4, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
+    net.cuda().train()
+    optim = driver.make_optimizer(net, cfg)
+    ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    xs, ys, xt = _sync_data(rank)
+    losses = driver.baseline_train_iteration(ddp, optim, (xs.cuda(), ys.cuda()), xt.cuda())
+    torch.cuda.synchronize()
+    st = net.backbone.state_dict()
+    q.put((rank, float(losses["loss_ce"]), {k: st[k].detach().cpu().numpy() for k in _SYNC_PROBE + _SYNC_STATS},
+           int(st["model.bn1.num_batches_tracked"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_two_ranks_match_one_process_on_the_concatenated_batch():
+    import socket
+    import torch.multiprocessing as mp
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_rank, args=(r, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    # oracle: one process, four crops
+    sd = N.resnet101_state(seed=4, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2)
+    d0, d1 = _sync_data(0), _sync_data(1)
+    xs, ys, xt = (torch.cat([a, b], 0) for a, b in zip(d0, d1))
+    ref = SacOracle(sd, cfg=dict(BASELINE=True))
+    l_ref = baseline_train_iteration(ref, SgdOracle(ref), (xs, ys), xt)
+    got = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    assert (got[0][1] + got[1][1]) / 2 == pytest.approx(l_ref["loss_ce"], rel=1e-4)
+    assert got[0][1] != pytest.approx(got[1][1], rel=1e-3)               # different data per rank
+    for r in range(2):
+        assert got[r][3] == 2
+        for k in _SYNC_STATS:
+            assert rel_err(got[r][2][k], ref.student[k]) < 1e-4, (r, k)
+        for k in _SYNC_PROBE:
+            # borderline ReLU units may move single tensors (test_gpu_models.py::test_resnet101_gradients_fp64_arbitration)
+            assert rel_err(got[r][2][k], ref.student[k].detach()) < 1e-3, (r, k)
+    for k in _SYNC_PROBE:
+        assert (got[0][2][k] == got[1][2][k]).all(), k

@@ -20,6 +20,7 @@ CASES = [
     ("7x7_s2_stem", 3, 64, [(7, 7, 1, 3)], 2, (2, 65, 49)),
     ("aspp4", 96, 19, [(3, 3, 6, 6), (3, 3, 12, 12), (3, 3, 18, 18), (3, 3, 24, 24)], 1, (2, 17, 21)),
     ("7x7_fcn_head", 16, 160, [(7, 7, 1, 3)], 1, (1, 8, 12)),
+    ("7x7_fcn_head_cfg5", 512, 4096, [(7, 7, 1, 3)], 1, (1, 16, 32)),     # fcn.py:49 at its cfg-5 size (512x1024 crop / 32)
 ]
 
 

@@ -41,10 +41,15 @@ def test_resnet101_eval_bn_golden_g2(golden):
     assert rel_err(sampled(outs["logits_up"], 512), g["eval_logits_up_s"]) < 1e-4
     assert rel_err(losses["loss_ce"], g["eval_loss"]) < 1e-5
     named = dict(net.named_parameters())
+    worst = []
     for k in [k[len("eval_g_"):] for k in g.files if k.startswith("eval_g_")]:
-        gn = float(g["eval_gn_" + k])
+        gn, gm = float(g["eval_gn_" + k]), float(g["eval_gm_" + k])
         assert abs(float(named[k].grad.norm()) - gn) < 1e-3 * gn, k
-        assert float((sampled(named[k].grad).cpu() - T(g["eval_g_" + k])).abs().max()) < 1e-3 * gn + 1e-7, k
+        assert abs(float(named[k].grad.abs().max()) - gm) < 1e-3 * gm, k
+        worst.append((float((sampled(named[k].grad).cpu() - T(g["eval_g_" + k])).abs().max()) / gm, k))
+    worst.sort(reverse=True)
+    print("g2 eval: sampled gradient error / tensor max:", worst[:3])
+    assert worst[0][0] < 1e-3, worst[:3]          # north_star: 1e-3 of the tensor max
 
 
 def _all_grads(seed, share_masks):
@@ -91,12 +96,96 @@ def test_resnet101_all_gradients_vs_oracle(seed):
     assert errs[0][0] < 2e-5, errs[:3]
 
 
+class _RecordingRelu:
+    """ReLU that keeps its pre-activations (call order = the engine's fused conv+ReLU op order)."""
+
+    def __init__(self):
+        self.z = []
+
+    def __call__(self, z):
+        self.z.append(z.detach())
+        return torch.relu(z)
+
+
+def _oracle_grads(sd, x, y, dtype, act=None):
+    ref = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for k in N.trainable_keys(ref):
+        ref[k].requires_grad_(True)
+    kw = {} if act is None else dict(act=act)
+    losses, _ = N.segnet_forward("deeplabv2_resnet101", ref, x.to(dtype), y, **kw)
+    losses["loss_ce"].sum().backward()
+    return {k: ref[k].grad for k in N.trainable_keys(ref)}, float(losses["loss_ce"].detach())
+
+
+@pytest.mark.parametrize("seed", [5])
+def test_resnet101_gradients_fp64_arbitration(seed):
+    """WITHOUT sharing ReLU patterns the HIP gradients and ATen-CPU fp32 autograd differ by up to ~1e-2 of a tensor's
+    max on a few parameters.  A float64 run of the oracle arbitrates:
+      1. the ReLU units on which the HIP forward and the fp64 forward disagree are a handful in ~5 million, and every
+         one of them has an fp64 pre-activation within fp32 round-off of zero (|z| <= 1e-5 of its layer's max): which
+         side of zero such a unit lands on is decided by the summation order of ANY fp32 implementation (ATen's own
+         fp32 run has such units too -- just different ones);
+      2. with the pattern fixed to what each fp32 implementation actually computed, both sit at fp32 round-off from
+         the fp64 gradients, per parameter and relative to that parameter's max (north_star's metric), and the HIP
+         path is no further from fp64 than twice ATen's fp32 (+1e-5).
+    So the un-shared comparison measures borderline units, not arithmetic; every gradient assertion elsewhere in tests/
+    that is looser than 1e-3 of the max cites this test."""
+    import models
+    sd = N.resnet101_state(seed=seed, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 3, 41, 57, generator=g)
+    y = torch.randint(0, 19, (2, 41, 57), generator=g)
+    y[:, :3] = 255
+    net = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=True)
+    net.load_state_dict(sd, strict=True)
+    net.cuda().train()
+    l_hip, _ = net(x.cuda(), y.cuda())
+    l_hip["loss_ce"].mean().backward()
+    hip = {k: p.grad.double().cpu() for k, p in net.named_parameters()}
+    eng = net._engine
+    _, saved = eng.forward(x.cuda(), keep=True)
+    hip_masks = [(saved["acts"][op.dst] > 0).cpu() for op in eng.plan.ops if op.kind == "conv" and op.relu]
+
+    # fp64, free-running: where do the patterns differ, and how close to zero are those units?
+    rec64 = _RecordingRelu()
+    g64, l64 = _oracle_grads(sd, x, y, torch.float64, rec64)
+    rec32 = _RecordingRelu()
+    g32, _ = _oracle_grads(sd, x, y, torch.float32, rec32)
+    assert abs(float(l_hip["loss_ce"]) - l64) < 1e-5 * abs(l64)
+    total = flips_hip = flips_aten = 0
+    worst = 0.0
+    for z64, m_hip, z32 in zip(rec64.z, hip_masks, rec32.z):
+        total += z64.numel()
+        d = (z64 > 0) != m_hip
+        flips_hip += int(d.sum())
+        flips_aten += int(((z64 > 0) != (z32 > 0)).sum())
+        if d.any():
+            worst = max(worst, float(z64[d].abs().max() / z64.abs().max()))
+    print("fp64 arbitration: %d ReLU units, HIP flips %d (worst |z|/max %.2e), ATen-fp32 flips %d" % (total, flips_hip, worst, flips_aten))
+    assert len(rec64.z) == len(hip_masks) and total > 3e6
+    assert flips_hip <= 1e-5 * total and worst <= 1e-5
+
+    # each fp32 implementation against fp64 with ITS OWN pattern
+    g64_hip, _ = _oracle_grads(sd, x, y, torch.float64, N.MaskedRelu(hip_masks))
+    g64_aten, _ = _oracle_grads(sd, x, y, torch.float64, N.MaskedRelu([z > 0 for z in rec32.z]))
+    rows = []
+    for k in hip:
+        e_hip = rel_err(hip[k], g64_hip[k])
+        e_aten = rel_err(g32[k], g64_aten[k])
+        rows.append((e_hip / (2 * e_aten + 1e-5), e_hip, e_aten, k))
+    rows.sort(reverse=True)
+    print("fp64 arbitration, worst parameters (ratio, err HIP, err ATen-fp32):", rows[:3])
+    assert len(rows) == 320
+    assert rows[0][0] <= 1.0, rows[:3]
+    assert max(r[1] for r in rows) < 1e-4
+    # and the free-running comparison really is explained by the flips: un-shared error >> shared error only if flips exist
+    free = max(rel_err(hip[k], g64[k]) for k in hip)
+    assert free < 5e-2 and (flips_hip > 0 or free < 1e-4), (free, flips_hip)
+
+
 def test_resnet101_gradients_with_borderline_relu():
-    """Same comparison WITHOUT sharing the masks: whenever a block-output pre-activation sits within fp32 round-off
-    of zero, the MFMA chain and ATen's CPU kernel may round it to opposite signs; the ReLU derivative of that
-    single unit flips and every gradient upstream of it moves by up to ~1e-2 of its max (an fp64 run puts ATen's
-    fp32 on the fp64 side -- any change of summation order does this, also between cuDNN algorithms).  The typical
-    parameter still agrees to ~1e-3; nothing blows up."""
+    """The free-running comparison documented (bound explained by test_resnet101_gradients_fp64_arbitration): the typical
+    parameter agrees to ~1e-3 of its max, single tensors upstream of a flipped unit move by up to ~1e-2; nothing blows up."""
     errs, _ = _all_grads(5, share_masks=False)
     med = errs[len(errs) // 2][0]
     assert med < 5e-3 and errs[0][0] < 5e-2, (errs[:3], med)
@@ -136,6 +225,76 @@ def test_fcn8s_golden_g10(golden):
     assert rel_err(sampled(named["vgg_head.0.weight"].grad), g["g_head0"]) < 2e-3
     assert rel_err(named["score_pool3.weight"].grad.reshape(-1)[:64], g["g_sp3"]) < 2e-3
     assert rel_err(sampled(named["block1.0.weight"].grad), g["g_first"]) < 2e-3
+
+
+def test_fcn8s_dropout2d_with_injected_masks_vs_oracle():
+    """fcn.py:52,56 Dropout2d(p=.1) in train mode: with the same per-(n, c) keep masks injected on both sides
+    (`module.keep_mask` here, `drop_masks` in the oracle) forward and gradients must agree (K19)."""
+    import models
+    sd = N.fcn8s_vgg16_state(seed=12, randomize_bn=True)
+    net = models.VGG16_FCN8s(19, criterion=CRIT, use_bn=True, freeze_bn=True, drop_rate=0.1)
+    net.load_state_dict(sd, strict=True)
+    net.cuda().train()
+    drops = [m for m in net.vgg_head if isinstance(m, nn.Dropout2d)]
+    assert len(drops) == 2 and all(m.p == 0.1 and m.training for m in drops)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    y = torch.randint(0, 19, (2, 64, 96), generator=g)
+    masks = [(torch.rand(2, 4096, generator=g) >= 0.1).float() / 0.9 for _ in drops]
+    assert all(0 < float((m == 0).float().mean()) < 0.2 for m in masks)
+    for m, k in zip(drops, masks):
+        m.keep_mask = k.cuda()
+    losses, outs = net(x.cuda(), y.cuda())
+    losses["loss_ce"].mean().backward()
+    ref = {k: v.clone() for k, v in sd.items()}
+    for k in N.trainable_keys(ref):
+        ref[k].requires_grad_(True)
+    l_ref, o_ref = N.segnet_forward("fcn_vgg16_bn", ref, x, y, drop_masks=[k.view(2, 4096, 1, 1) for k in masks])
+    l_ref["loss_ce"].sum().backward()
+    assert rel_err(outs["logits_up"], o_ref["logits_up"]) < 1e-4
+    assert rel_err(losses["loss_ce"], l_ref["loss_ce"]) < 1e-5
+    named = dict(net.named_parameters())
+    for k in ("vgg_head.0.weight", "vgg_head.1.weight", "vgg_head.4.weight", "vgg_head.4.bias", "vgg_head.8.weight", "block3.40.weight"):
+        assert rel_err(named[k].grad, ref[k].grad) < 1e-3, k
+    # without an injected mask the draw is the module's own: a different pattern, same expectation machinery
+    for m in drops:
+        m.keep_mask = None
+    l2, _ = net(x.cuda(), y.cuda())
+    assert float(l2["loss_ce"]) != pytest.approx(float(losses["loss_ce"]), rel=1e-6)
+    net.eval()
+    with torch.no_grad():
+        e1, _ = net(x.cuda())
+        e2, _ = net(x.cuda())
+    assert torch.equal(e1, e2)
+
+
+def test_sac_pool_functions_callable_and_engine_follows_replaced_parameters():
+    """API surface of sac.py:49,218-269: `pool_func` is callable on its own; and an Engine captured before a parameter
+    OBJECT was replaced (load_state_dict(assign=True) / m.weight = nn.Parameter(...)) must not keep running the old one."""
+    import models
+    from oracle import head_ref as H
+    cfg = model_cfg()
+    net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT).cuda().train()
+    g = torch.Generator().manual_seed(77)
+    aligned = torch.softmax(torch.randn(4, 19, 17, 23, generator=g) * 2, 1) * torch.rand(4, 1, 17, 23, generator=g)
+    aligned[1, :, :3] = 0.0
+    pooled, mask = net.pool_func(aligned.cuda(), 2)
+    p_ref, m_ref = H.avg_pool_views(aligned, 2)
+    assert net.pool_func == net._avg_pool and rel_err(pooled, p_ref) < 1e-6 and torch.equal(mask.cpu(), m_ref)
+    a2 = aligned.clone().cuda()
+    pooled, mask = net._minentropy_pool(a2, 2)
+    p_ref, m_ref = H.minentropy_pool_views(aligned.clone(), 2)
+    assert rel_err(pooled, p_ref) < 1e-6 and torch.equal(mask.cpu(), m_ref) and pooled.data_ptr() == a2.data_ptr()
+    with pytest.raises(RuntimeError):
+        net._minentropy_pool(aligned[:3].cuda(), 2)
+    # replaced parameter object
+    x = torch.randn(1, 3, 33, 49, device="cuda")
+    with torch.no_grad():
+        l0, _ = net.backbone(x)
+        conv = net.backbone.model.layer5.conv2d_list[0]
+        conv.weight = nn.Parameter(conv.weight.detach() * 2.0)
+        l1, _ = net.backbone(x)
+    assert rel_err(l1, l0) > 1e-2
 
 
 def test_two_sac_training_steps_golden_g8(golden):

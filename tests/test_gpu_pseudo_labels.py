@@ -63,3 +63,38 @@ def test_errors_are_reported():
     from dasac_hip import ops, DasacError
     with pytest.raises(DasacError):
         ops.pseudo_labels(torch.rand(1, 19, 4, 4, device="cuda"), None, 0.75, 0.0)
+
+
+def test_labels_bit_equal_through_the_module_threshold_path(golden):
+    """sac.py:151-187 end to end on injected probabilities: the per-class discount 1 - exp(-chi/beta) comes from chi
+    through the product's own path (a 19-float host round trip evaluated by the CPU ATen kernels the reference uses), so
+    the thresholds and with them the int64 label map equal the reference's BIT FOR BIT -- golden g5 (captured from
+    the reference) and fresh seeded cases against the oracle."""
+    from types import SimpleNamespace as NS
+    import torch.nn as nn
+    import models
+    from oracle import head_ref as H
+    from oracle.step_ref import DEFAULT_CFG
+    g = golden("g5_pseudo_labels")
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False))
+    net = models.get_model(cfg, 0, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none")).cuda().train()
+    T = torch.from_numpy
+    net.running_conf.copy_(T(g["chi"]))
+    disc_here = net._threshold_discount().cpu()
+    assert torch.equal(disc_here, H.threshold_discount(T(g["chi"]), cfg.THRESHOLD_BETA))       # same host, same ATen kernels
+    assert torch.allclose(disc_here, T(g["discount"]), rtol=3e-7, atol=0)    # golden from another host: <= 1-2 ulp (Sleef ISA paths)
+    for tag, disc in (("disc", True), ("nodisc", False)):
+        lab, conf, idx = net._pseudo_labels_probs(T(g["probs"]).cuda(), T(g["ignore"]).cuda(), disc)
+        assert torch.equal(lab.cpu(), T(g["labels_" + tag])) and torch.equal(idx.cpu(), T(g["idx_" + tag]))
+        assert torch.equal(conf.cpu(), T(g["conf_" + tag]))
+    gen = torch.Generator().manual_seed(123)
+    for trial in range(4):
+        chi = torch.rand(19, generator=gen) * (0.004 if trial % 2 else 0.2)
+        probs = torch.softmax(torch.randn(2, 19, 97, 129, generator=gen) * (2 + trial), 1)
+        ignore = torch.rand(2, 97, 129, generator=gen) < 0.05
+        net.running_conf.copy_(chi)
+        lab, conf, _ = net._pseudo_labels_probs(probs.cuda(), ignore.cuda(), True)
+        ref_lab, ref_conf, _ = H.pseudo_labels(probs, ignore, cfg.RUN_CONF_UPPER, cfg.RUN_CONF_LOWER, H.threshold_discount(chi, cfg.THRESHOLD_BETA))
+        assert torch.equal(lab.cpu(), ref_lab) and torch.equal(conf.cpu(), ref_conf), trial
+        assert torch.equal(net._focal_weight(cfg.FOCAL_P).cpu(), H.focal_weight(chi, cfg.FOCAL_P))
+        assert int((ref_lab != 255).sum()) > 0
