@@ -38,13 +38,18 @@ def test_resnet101_train_bn_golden_g2(golden):
     assert rel_err(st["model.layer3.4.bn2.running_var"], g["train_rv_l3"]) < 1e-5
     assert int(st["model.bn1.num_batches_tracked"]) == int(g["train_nbt"])
     named = dict(net.named_parameters())
-    errs = []
+    errs, worst = [], []
     for k in [k[len("train_g_"):] for k in g.files if k.startswith("train_g_")]:
-        gn = float(g["train_gn_" + k])
+        gn, gm = float(g["train_gn_" + k]), float(g["train_gm_" + k])
         errs.append((abs(float(named[k].grad.norm()) - gn) / gn, k))
-        assert float((sampled(named[k].grad).cpu() - T(g["train_g_" + k])).abs().max()) < 2e-2 * gn + 1e-7, k
+        worst.append((float((sampled(named[k].grad).cpu() - T(g["train_g_" + k])).abs().max()) / gm, k))
     errs.sort(reverse=True)
-    assert errs[len(errs) // 2][0] < 1e-3, errs[:4]        # a borderline ReLU may move single tensors
+    worst.sort(reverse=True)
+    print("g2 train: sampled gradient error / tensor max:", worst[:3], "median", worst[len(worst) // 2])
+    # free-running fp32 vs fp32: single tensors upstream of a borderline ReLU unit move (fp64-arbitrated in
+    # test_gpu_models.py::test_resnet101_gradients_fp64_arbitration); the typical tensor is at round-off
+    assert errs[len(errs) // 2][0] < 1e-3, errs[:4]
+    assert worst[len(worst) // 2][0] < 1e-3 and worst[0][0] < 5e-2, worst[:4]
 
 
 def test_baseline_adabn_iteration_vs_oracle():
@@ -166,7 +171,7 @@ def test_syncbn_two_ranks_match_one_process_on_the_concatenated_batch():
         p_.join(120)
         assert p_.exitcode == 0
     assert (got[0][1] + got[1][1]) / 2 == pytest.approx(l_ref["loss_ce"], rel=1e-4)
-    assert got[0][1] != pytest.approx(got[1][1], rel=1e-3)               # different data per rank
+    assert abs(got[0][1] - got[1][1]) > 1e-4 * abs(got[0][1])           # different data per rank
     for r in range(2):
         assert got[r][3] == 2
         for k in _SYNC_STATS:

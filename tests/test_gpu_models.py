@@ -117,7 +117,7 @@ def _oracle_grads(sd, x, y, dtype, act=None):
     return {k: ref[k].grad for k in N.trainable_keys(ref)}, float(losses["loss_ce"].detach())
 
 
-@pytest.mark.parametrize("seed", [5])
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8])
 def test_resnet101_gradients_fp64_arbitration(seed):
     """WITHOUT sharing ReLU patterns the HIP gradients and ATen-CPU fp32 autograd differ by up to ~1e-2 of a tensor's
     max on a few parameters.  A float64 run of the oracle arbitrates:
@@ -177,7 +177,7 @@ def test_resnet101_gradients_fp64_arbitration(seed):
     print("fp64 arbitration, worst parameters (ratio, err HIP, err ATen-fp32):", rows[:3])
     assert len(rows) == 320
     assert rows[0][0] <= 1.0, rows[:3]
-    assert max(r[1] for r in rows) < 1e-4
+    assert max(r[1] for r in rows) < 2e-5          # measured 1.1e-6 (ATen fp32: 4e-7)
     # and the free-running comparison really is explained by the flips: un-shared error >> shared error only if flips exist
     free = max(rel_err(hip[k], g64[k]) for k in hip)
     assert free < 5e-2 and (flips_hip > 0 or free < 1e-4), (free, flips_hip)
@@ -292,7 +292,7 @@ def test_sac_pool_functions_callable_and_engine_follows_replaced_parameters():
     with torch.no_grad():
         l0, _ = net.backbone(x)
         conv = net.backbone.model.layer5.conv2d_list[0]
-        conv.weight = nn.Parameter(conv.weight.detach() * 2.0)
+        conv.weight = nn.Parameter(conv.weight.detach() * 50.0)
         l1, _ = net.backbone(x)
     assert rel_err(l1, l0) > 1e-2
 
