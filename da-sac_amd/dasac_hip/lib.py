@@ -60,6 +60,8 @@ PROTOTYPES = {
     "dasac_tap_scatter": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_conv_wgrad_finish_expanded": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "dasac_iou_counts": (_i, [_p, _p, _i, _i, _l, _i, _p, _p]),
+    "dasac_make_views_table_ints": (_i, [_i, _i]),
+    "dasac_make_views": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

@@ -268,6 +268,20 @@ int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const
 int dasac_iou_counts(const float* logits, const int64_t* gt, int B, int C, int64_t HW, int ignore_index,
                      int64_t* counts, dasac_stream_t stream);
 
+/* K augmented views of one target crop: the pixel work of DataTarget.__getitem__'s tail
+ * (datasets/dataloader_target.py:281-306) -- GuidedRandHFlip (datasets/tf_target.py:141-157), MaskRandScaleCrop
+ * (:159-239; Pillow resize BILINEAR for the image, NEAREST for label / padding mask) and ToTensorMask / Normalize /
+ * ApplyMask (:33-98) -- for all L views in one launch, byte-exact with Pillow's fixed-point resampling.
+ * image u8 [3,H,W] planar, label u8 [H,W], mask u8 [H,W] or NULL (0 = valid); `tables`: L rows of
+ * dasac_make_views_table_ints(H, W) int32 built on the host (views.py: view_tables): header {flip, ii, jj, win_h,
+ * win_w, identity, 0, 0}, bounds_h[W][2], coeff_h[W][8], bounds_v[H][2], coeff_v[H][8], nearest_x[W], nearest_y[H].
+ * mean3 / std3: HOST arrays of 3 floats.  Outputs: frames f32 [L,3,H,W] (normalised, 0 under the mask), gt i64
+ * [L,H,W] (ignore_label under the mask), views_u8 (optional) u8 [L,3,H,W] = the resampled bytes. */
+int dasac_make_views_table_ints(int H, int W);
+int dasac_make_views(const uint8_t* image, const uint8_t* label, const uint8_t* mask, int H, int W, int L,
+                     const int32_t* tables, const float* mean3, const float* std3, int ignore_label, float* frames,
+                     int64_t* gt, uint8_t* views_u8, dasac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

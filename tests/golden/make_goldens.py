@@ -418,9 +418,85 @@ def g11_index_tables():
     save("g11_index_tables", **rec)
 
 
+# ------------------------------------------------------------------------------------------------
+# G12: the K augmented views of one target crop through the reference's own transform classes
+# (datasets/tf_target.py: GuidedRandHFlip :141-157, MaskRandScaleCrop :159-239, ToTensorMask/Normalize/ApplyMask
+# :33-98) on PIL images, python `random` seeded.  torchvision is absent here; the four functional helpers the
+# classes call are one-line wrappers over Pillow / torch and are stood in for as such (crop, hflip, pad, to_tensor).
+# ------------------------------------------------------------------------------------------------
+def _install_tv_functional():
+    from PIL import Image, ImageOps
+    F_ = sys.modules["torchvision.transforms.functional"]
+    F_.crop = lambda img, top, left, h, w: img.crop((left, top, left + w, top + h))
+    F_.hflip = lambda img: img.transpose(Image.FLIP_LEFT_RIGHT)
+    F_.pad = lambda img, padding, fill=0, padding_mode="constant": ImageOps.expand(img, border=tuple(padding), fill=fill)
+    F_.to_tensor = lambda pic: torch.from_numpy(np.array(pic, np.uint8, copy=True)).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+
+def g12_views():
+    import random
+    from PIL import Image
+    _install_tv_functional()
+    import datasets.tf_target as tft
+    from datasets.dataloader_target import DataTarget
+    from datasets.dataloader_base import DLBase
+
+    class _Numpy1:
+        """tf_target.py:36 calls np.array(pic, np.int32, copy=False), which NumPy 2 (this image: 2.2) rejects when a copy
+        is needed; NumPy 1.x -- what the reference was written for -- copied silently (= np.asarray)."""
+
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def array(obj, dtype=None, copy=True):
+            return np.array(obj, dtype) if copy else np.asarray(obj, dtype)
+    tft.np = _Numpy1()
+    base = DLBase()
+    rec = dict(mean=np.array(base.MEAN), std=np.array(base.STD))
+    H, W, L = 64, 96, 4
+    for case, (zoom, seed) in enumerate((((0.5, 1.0), 121), ((0.5, 1.2), 7), ((0.5, 1.0), 5))):
+        gen = np.random.RandomState(seed)
+        # a smooth image (so that bilinear taps matter), block labels, a padded margin in the mask (MaskRandCrop fill=1)
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = np.stack([(127 + 120 * np.sin(xx / (3.0 + c) + yy / 5.0) + gen.randint(-6, 7, (H, W))).clip(0, 255) for c in range(3)], -1).astype(np.uint8)
+        lab = (gen.randint(0, 19, (H // 8, W // 8)).repeat(8, 0).repeat(8, 1)).astype(np.uint8)
+        msk = np.zeros((H, W), np.uint8)
+        msk[:, W - 7:] = 1
+        msk[:3] = 1
+        images = [Image.fromarray(img) for _ in range(L)]
+        labels = [Image.fromarray(lab, "L") for _ in range(L)]
+        masks = [Image.fromarray(msk, "L") for _ in range(L)]
+        random.seed(1000 + seed)
+        out = tft.GuidedRandHFlip()(images, labels, masks)
+        images, labels, masks, params = tft.MaskRandScaleCrop(list(zoom))(*out)
+        u8 = np.stack([np.array(im) for im in images])
+        lab_u8 = np.stack([np.array(x) for x in labels])
+        msk_u8 = np.stack([np.array(x) for x in masks])
+        post = tft.Compose([tft.ToTensorMask(), tft.Normalize(mean=base.MEAN, std=base.STD), tft.ApplyMask(-1)])
+        frames, gts = post(images, labels, masks)
+        cfg_from_file("/root/reference/configs/deeplabv2_resnet101_train.yaml")
+        ref_cfg.DATASET.CROP_SIZE, ref_cfg.TRAIN.GROUP_SIZE = [H, W], L
+
+        class _Shim:
+            cfg = ref_cfg
+        aff = DataTarget._get_affine(_Shim, params)
+        inv = DataTarget._get_affine_inv(_Shim, aff, params)
+        ref_cfg.DATASET.CROP_SIZE, ref_cfg.TRAIN.GROUP_SIZE = [512, 1024], 4
+        t = "c%d_" % case
+        rec.update({t + "image": img, t + "label": lab, t + "mask": msk, t + "zoom": np.array(zoom), t + "seed": 1000 + seed,
+                    t + "params": np.array(params, dtype=np.float64), t + "views_u8": u8, t + "labels_u8": lab_u8, t + "masks_u8": msk_u8,
+                    t + "gt": torch.stack(gts).to(torch.int16), t + "affine": aff, t + "affine_inv": inv})
+        if case < 2:
+            rec[t + "frames"] = torch.stack(frames)
+        print("case", case, "params", params)
+    rec["n_cases"] = 3
+    save("g12_views", **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11"]
+    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11", "g12"]
     table = dict(g3=g3_bilinear, g4=g4_refine, g5=g5_pseudo_labels, g6=g6_losses, g7=g7_state_sequences,
-                 g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture, g11=g11_index_tables)
+                 g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture, g11=g11_index_tables, g12=g12_views)
     for w in which:
         table[w]()
