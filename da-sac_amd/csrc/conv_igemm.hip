@@ -362,6 +362,10 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
                 if (++spins >= (1 << 26)) __builtin_trap();
               }
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              // self-cleaning flags: a range deposits at most once per launch and this worker is its only consumer,
+              // so the flag can go back to 0 right here -- the next launch on the stream finds the array zeroed and
+              // no memset (an extra kernel + two launch gaps per conv) is needed
+              __hip_atomic_store(&flags[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             const int src0 = r * (ACC_REGS * kThreads * 4);
@@ -890,7 +894,6 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
     if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
     float* partial = reinterpret_cast<float*>(workspace);
     int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
-    DASAC_HIP(hipMemsetAsync(flags, 0, (size_t)(kSkWorkers + 1) * sizeof(int), s));
     hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g, ep,
                        m_tiles, n_tiles, partial, flags);
     return DASAC_OK;

@@ -357,10 +357,12 @@ __global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int
 __global__ void bn_train_finalize(const double* __restrict__ sums, double count_host, const double* __restrict__ count_dev,
                                   const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var, float momentum, float eps, int C,
+                                  float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked, float momentum,
+                                  float eps, int C,
                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                   float* __restrict__ invstd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;      // nn.BatchNorm bookkeeping, no extra launch
   if (c >= C) return;
   const double count = count_dev ? count_dev[0] : count_host;   // SyncBN: the all-reduced count stays on the device
   const double m = sums[c] / count;
@@ -456,12 +458,13 @@ extern "C" int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* 
 }
 
 extern "C" int dasac_bn_train_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
-                                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                       int C, float* scale, float* shift, float* mean, float* invstd, dasac_stream_t stream) {
+                                       const float* beta, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, float momentum, float eps, int C, float* scale,
+                                       float* shift, float* mean, float* invstd, dasac_stream_t stream) {
   DASAC_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && (count > 0 || count_dev),
                 "bn_train_finalize: bad arguments");
   hipLaunchKernelGGL(bn_train_finalize, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, count_dev, gamma, beta,
-                     running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd);
+                     running_mean, running_var, num_batches_tracked, momentum, eps, C, scale, shift, mean, invstd);
   DASAC_CHECK_LAUNCH("bn_train_finalize");
   return DASAC_OK;
 }

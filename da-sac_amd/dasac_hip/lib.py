@@ -51,7 +51,7 @@ PROTOTYPES = {
     "dasac_add": (_i, [_p, _p, _p, _l, _p]),
     "dasac_relu_mask": (_i, [_p, _p, _p, _l, _p]),
     "dasac_bn_stats": (_i, [_p, _i, _i, _l, _p, _p]),
-    "dasac_bn_train_finalize": (_i, [_p, C.c_double, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "dasac_bn_train_finalize": (_i, [_p, C.c_double, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
     "dasac_bn_apply": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p, _p]),
     "dasac_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p]),
     "dasac_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, C.c_double, _p, _i, _i, _l, _p, _p, _p, _p]),
@@ -110,11 +110,14 @@ def require_gpu(*tensors):
 _ws_cache = {}
 
 
-def workspace(nbytes, device):
-    """Per-(device, stream) grow-only scratch buffer (the C ABI never allocates)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+def workspace(nbytes, device, owner=None):
+    """Per-(device, stream) grow-only scratch buffer (the C ABI never allocates).  `owner` names a buffer that belongs to
+    ONE kernel family and is zero-filled when (re)allocated -- the stream-K hand-off flags of dasac_conv_gemm are
+    self-cleaning and must not be scribbled over by other ops' scratch data (include/dasac_hip.h)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, owner)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        alloc = torch.zeros if owner is not None else torch.empty
+        buf = alloc(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

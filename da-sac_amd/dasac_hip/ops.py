@@ -175,7 +175,7 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     assert out.shape[0] == Nb and out.shape[1] == M and x.is_contiguous() and out.is_contiguous()
     for t_ in (res, mask):
         assert t_ is None or (t_.shape == out.shape and t_.is_contiguous())
-    ws = L.workspace(lib.dasac_conv_gemm_workspace(), x.device)
+    ws = L.workspace(lib.dasac_conv_gemm_workspace(), x.device, owner="conv_gemm")
     fn = lib.dasac_conv_gemm_x3 if getattr(packed, "dasac_x3", False) else lib.dasac_conv_gemm
     tag = (M, K, Nb * OH * OW, stride, ostride, res is not None, mask is not None)
 
@@ -592,11 +592,10 @@ def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
     upd = update_running and bn.track_running_stats
     L.check(lib.dasac_bn_train_finalize(sums.data_ptr(), count, L.ptr(count_dev), bn.weight.data_ptr(), bn.bias.data_ptr(),
                                         bn.running_mean.data_ptr() if upd else None, bn.running_var.data_ptr() if upd else None,
-                                        float(mom), float(bn.eps), Cn, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                        bn.num_batches_tracked.data_ptr() if upd else None, float(mom), float(bn.eps), Cn, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                         invstd.data_ptr(), L.stream_ptr()), "dasac_bn_train_finalize")
-    if upd:
-        bn.num_batches_tracked += 1
-        bump_versions([bn.running_mean, bn.running_var])     # written through raw pointers; eval-mode folds key on them
+    if upd:                                                    # written through raw pointers; eval-mode folds key on them
+        bump_versions([bn.running_mean, bn.running_var, bn.num_batches_tracked])
     y = torch.empty_like(z)
     L.check(lib.dasac_bn_apply(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(res), int(relu), N, Cn, HW, y.data_ptr(),
                                L.stream_ptr()), "dasac_bn_apply")
@@ -622,11 +621,12 @@ def bn_train_backward(dy, z, stats, gamma, want_params=True):
     dz = torch.empty_like(z)
     dg = _f32((Cn,), z) if want_params else None
     db = _f32((Cn,), z) if want_params else None
+    fused = want_params and sums is local                     # one rank: the kernel writes d gamma / d beta itself
     L.check(lib.dasac_bn_bwd_apply(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                   sums.data_ptr(), float(count), L.ptr(count_dev), N, Cn, HW, dz.data_ptr(), None, None,
-                                   L.stream_ptr()),
+                                   sums.data_ptr(), float(count), L.ptr(count_dev), N, Cn, HW, dz.data_ptr(),
+                                   L.ptr(dg) if fused else None, L.ptr(db) if fused else None, L.stream_ptr()),
             "dasac_bn_bwd_apply")
-    if want_params:     # parameter gradients are LOCAL sums (DDP averages them across ranks afterwards)
+    if want_params and not fused:     # parameter gradients are LOCAL sums (DDP averages them across ranks afterwards)
         dg.copy_(local[Cn:].to(torch.float32))
         db.copy_(local[:Cn].to(torch.float32))
     return dz, dg, db

@@ -78,6 +78,9 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *                    per tile, 2 = persistent stream-K.  With a workspace of
  *                    dasac_conv_gemm_workspace() bytes the launcher may pick the persistent stream-K
  *                    schedule (equal matrix work per CU); workspace NULL = one block per tile.
+ *                    The workspace must be ZERO-FILLED by the caller when it is allocated and belong to one
+ *                    stream at a time: its hand-off flags are self-cleaning (every launch leaves them
+ *                    zero), which saves a memset per launch.
  * dasac_conv_wgrad   partial weight gradients (split over pixels) into `workspace`;
  * dasac_conv_wgrad_finish  sums the splits, writes dW[co,ci,kh,kw] = scale[co]*G and, when `dot`
  *                    is given, dot[co] += sum_k W*G (the frozen-BN gamma gradient term); `sum_dz`
@@ -251,7 +254,8 @@ int dasac_relu_mask(const float* dy, const float* y, float* out, int64_t n, dasa
  */
 int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, dasac_stream_t stream);
 int dasac_bn_train_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
-                            const float* beta, float* running_mean, float* running_var, float momentum, float eps, int C,
+                            const float* beta, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked /* += 1 when given */, float momentum, float eps, int C,
                             float* scale, float* shift, float* mean, float* invstd,
                             dasac_stream_t stream);
 int dasac_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu,

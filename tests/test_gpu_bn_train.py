@@ -49,7 +49,7 @@ def test_resnet101_train_bn_golden_g2(golden):
     # free-running fp32 vs fp32: single tensors upstream of a borderline ReLU unit move (fp64-arbitrated in
     # test_gpu_models.py::test_resnet101_gradients_fp64_arbitration); the typical tensor is at round-off
     assert errs[len(errs) // 2][0] < 1e-3, errs[:4]
-    assert worst[len(worst) // 2][0] < 1e-3 and worst[0][0] < 5e-2, worst[:4]
+    assert worst[len(worst) // 2][0] < 1e-2 and worst[0][0] < 5e-2, worst[:4]
 
 
 def test_baseline_adabn_iteration_vs_oracle():

@@ -107,18 +107,18 @@ class _RecordingRelu:
         return torch.relu(z)
 
 
-def _oracle_grads(sd, x, y, dtype, act=None):
+def _oracle_grads(sd, x, y, dtype, act=None, bn_train=False):
     ref = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     for k in N.trainable_keys(ref):
         ref[k].requires_grad_(True)
     kw = {} if act is None else dict(act=act)
-    losses, _ = N.segnet_forward("deeplabv2_resnet101", ref, x.to(dtype), y, **kw)
+    losses, _ = N.segnet_forward("deeplabv2_resnet101", ref, x.to(dtype), y, bn_train=bn_train, **kw)
     losses["loss_ce"].sum().backward()
     return {k: ref[k].grad for k in N.trainable_keys(ref)}, float(losses["loss_ce"].detach())
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8])
-def test_resnet101_gradients_fp64_arbitration(seed):
+@pytest.mark.parametrize("seed,bn_train", [(1, False), (2, False), (3, False), (5, False), (8, False), (2, True), (6, True)])
+def test_resnet101_gradients_fp64_arbitration(seed, bn_train):
     """WITHOUT sharing ReLU patterns the HIP gradients and ATen-CPU fp32 autograd differ by up to ~1e-2 of a tensor's
     max on a few parameters.  A float64 run of the oracle arbitrates:
       1. the ReLU units on which the HIP forward and the fp64 forward disagree are a handful in ~5 million, and every
@@ -129,14 +129,18 @@ def test_resnet101_gradients_fp64_arbitration(seed):
          the fp64 gradients, per parameter and relative to that parameter's max (north_star's metric), and the HIP
          path is no further from fp64 than twice ATen's fp32 (+1e-5).
     So the un-shared comparison measures borderline units, not arithmetic; every gradient assertion elsewhere in tests/
-    that is looser than 1e-3 of the max cites this test."""
+    that is looser than 1e-3 of the max cites this test.
+    bn_train: the same with batch-statistics BN (baseline / AdaBN mode, 2 x 33 x 49 crops as in golden g2 'train'): a
+    handful of samples per channel at stride 8 make the normalisation ill-conditioned, so BOTH fp32 implementations sit
+    further from fp64 -- the bound is relative to ATen's own fp32 error, whatever that is."""
     import models
     sd = N.resnet101_state(seed=seed, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2)
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(2, 3, 41, 57, generator=g)
-    y = torch.randint(0, 19, (2, 41, 57), generator=g)
+    hw = (33, 49) if bn_train else (41, 57)
+    x = torch.randn(2, 3, *hw, generator=g)
+    y = torch.randint(0, 19, (2,) + hw, generator=g)
     y[:, :3] = 255
-    net = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=True)
+    net = models.DeepLabV2_ResNet101(num_classes=19, criterion=CRIT, freeze_bn=not bn_train)
     net.load_state_dict(sd, strict=True)
     net.cuda().train()
     l_hip, _ = net(x.cuda(), y.cuda())
@@ -148,9 +152,9 @@ def test_resnet101_gradients_fp64_arbitration(seed):
 
     # fp64, free-running: where do the patterns differ, and how close to zero are those units?
     rec64 = _RecordingRelu()
-    g64, l64 = _oracle_grads(sd, x, y, torch.float64, rec64)
+    g64, l64 = _oracle_grads(sd, x, y, torch.float64, rec64, bn_train)
     rec32 = _RecordingRelu()
-    g32, _ = _oracle_grads(sd, x, y, torch.float32, rec32)
+    g32, _ = _oracle_grads(sd, x, y, torch.float32, rec32, bn_train)
     assert abs(float(l_hip["loss_ce"]) - l64) < 1e-5 * abs(l64)
     total = flips_hip = flips_aten = 0
     worst = 0.0
@@ -161,26 +165,31 @@ def test_resnet101_gradients_fp64_arbitration(seed):
         flips_aten += int(((z64 > 0) != (z32 > 0)).sum())
         if d.any():
             worst = max(worst, float(z64[d].abs().max() / z64.abs().max()))
-    print("fp64 arbitration: %d ReLU units, HIP flips %d (worst |z|/max %.2e), ATen-fp32 flips %d" % (total, flips_hip, worst, flips_aten))
-    assert len(rec64.z) == len(hip_masks) and total > 3e6
-    assert flips_hip <= 1e-5 * total and worst <= 1e-5
+    print("fp64 arbitration%s: %d ReLU units, HIP flips %d (worst |z|/max %.2e), ATen-fp32 flips %d" % (
+        " [train-mode BN]" if bn_train else "", total, flips_hip, worst, flips_aten))
+    assert len(rec64.z) == len(hip_masks) and total > 2e6
+    assert flips_hip <= (1e-4 if bn_train else 1e-5) * total and worst <= (1e-4 if bn_train else 1e-5)
 
     # each fp32 implementation against fp64 with ITS OWN pattern
-    g64_hip, _ = _oracle_grads(sd, x, y, torch.float64, N.MaskedRelu(hip_masks))
-    g64_aten, _ = _oracle_grads(sd, x, y, torch.float64, N.MaskedRelu([z > 0 for z in rec32.z]))
+    g64_hip, _ = _oracle_grads(sd, x, y, torch.float64, N.MaskedRelu(hip_masks), bn_train)
+    g64_aten, _ = _oracle_grads(sd, x, y, torch.float64, N.MaskedRelu([z > 0 for z in rec32.z]), bn_train)
     rows = []
     for k in hip:
         e_hip = rel_err(hip[k], g64_hip[k])
         e_aten = rel_err(g32[k], g64_aten[k])
         rows.append((e_hip / (2 * e_aten + 1e-5), e_hip, e_aten, k))
     rows.sort(reverse=True)
-    print("fp64 arbitration, worst parameters (ratio, err HIP, err ATen-fp32):", rows[:3])
+    free = max(rel_err(hip[k], g64[k]) for k in hip)
+    free_aten = max(rel_err(g32[k], g64[k]) for k in hip)
+    print("fp64 arbitration, worst parameters (ratio, err HIP, err ATen-fp32):", rows[:3], "free-running max err: HIP %.2e ATen %.2e" % (free, free_aten))
     assert len(rows) == 320
     assert rows[0][0] <= 1.0, rows[:3]
-    assert max(r[1] for r in rows) < 2e-5          # measured 1.1e-6 (ATen fp32: 4e-7)
+    if not bn_train:
+        assert max(r[1] for r in rows) < 2e-5          # measured 1.1e-6 (ATen fp32: 4e-7)
     # and the free-running comparison really is explained by the flips: un-shared error >> shared error only if flips exist
-    free = max(rel_err(hip[k], g64[k]) for k in hip)
-    assert free < 5e-2 and (flips_hip > 0 or free < 1e-4), (free, flips_hip)
+    # measured: frozen BN -- HIP 1e-6 .. 1.7e-2, ATen-fp32 7e-7 .. 1.7e-2 (whoever has flipped units is off, either side);
+    # batch-statistics BN at 2 x 33 x 49 -- BOTH 0.09 .. 0.14 with 3-8 flipped units each (ill-conditioned statistics)
+    assert free < (0.5 if bn_train else 5e-2) and (flips_hip > 0 or free < (1e-2 if bn_train else 1e-4)), (free, flips_hip)
 
 
 def test_resnet101_gradients_with_borderline_relu():
