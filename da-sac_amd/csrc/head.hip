@@ -11,6 +11,8 @@
 //   class_state        models/sac.py:104-117,120,151-152                  running class prior, discount, focal weights
 #include "common.hpp"
 
+#include <atomic>
+
 namespace dasac {
 
 constexpr int kMaxC = 32;   // classes held in registers
@@ -33,20 +35,23 @@ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
   return t;
 }
 
-// one thread per high-res pixel, loop over classes.  Optional outputs:
+// Four consecutive high-res pixels of one row per thread, loop over classes.  Optional outputs:
 //   up    [B,C,H,W]  upsampled logits
 //   probs [B,C,H,W]  softmax(up) * (ignore ? 0 : 1)
 //   csum  [C] double class sums of the UNMASKED softmax (running class prior, sac.py:108)
-// CT = compile-time class count (19 for Cityscapes) so the per-pixel class vector stays in registers.
-template <int CT>
+// CT = compile-time class count (19 for Cityscapes) so the per-pixel class vectors stay in registers.
+// HBM-bound: 76 B written per pixel and output.  Four pixels per thread make every store a (4-byte aligned) dwordx4 and
+// let the pixels share their low-resolution taps: at the 8x factor of the backbone the four x positions touch at most
+// three low-res columns, so a class costs 6 L1/L2 loads per 4 pixels instead of 16.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int CT, bool SOFTMAX>
 __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict__ x, int Crt, int h, int w, int H, int W,
                                                         float sh, float sw, const uint8_t* __restrict__ ignore,
                                                         float* __restrict__ up, float* __restrict__ probs,
-                                                        double* __restrict__ csum, int blocks_per_image) {
+                                                        double* __restrict__ csum, int64_t items) {
   const int C = CT < kMaxC ? CT : Crt;          // CT == kMaxC is the generic (runtime-C) instantiation
-  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
-  const int HW = H * W, hw = h * w;
-  const float* xb = x + (size_t)b * C * hw;
+  const int HW = H * W, hw = h * w, Wq = (W + 3) >> 2;
   __shared__ float s_sum[kMaxC];
   if (csum) {
     if (threadIdx.x < kMaxC) s_sum[threadIdx.x] = 0.f;
@@ -55,52 +60,126 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
   float acc[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) acc[c] = 0.f;
-  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
-    const int oy = p / W, ox = p - oy * W;
-    const Tap ty = tap_ac(oy, sh, h), tx = tap_ac(ox, sw, w);
-    const int o00 = ty.i0 * w + tx.i0, o01 = ty.i0 * w + tx.i1, o10 = ty.i1 * w + tx.i0, o11 = ty.i1 * w + tx.i1;
-    float v[CT];
-    float mx = -INFINITY;
+  for (int64_t it = (int64_t)blockIdx.x * kHB + threadIdx.x; it < items; it += (int64_t)gridDim.x * kHB) {
+    const int q = (int)(it % Wq);
+    const int64_t row = it / Wq;                 // b*H + y
+    const int oy = (int)(row % H), b = (int)(row / H);
+    const int ox = q * 4, nx = min(4, W - ox);
+    const float* xb = x + (size_t)b * C * hw;
+    const Tap ty = tap_ac(oy, sh, h);
+    Tap tx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tx[e] = tap_ac(min(ox + e, W - 1), sw, w);
+    const int c_lo = tx[0].i0;
+    const bool narrow = tx[3].i1 - c_lo <= 2;               // the usual case: <= 3 low-res columns under the 4 pixels
+    const int r0 = ty.i0 * w, r1 = ty.i1 * w;
+    const int k1 = min(c_lo + 1, w - 1), k2 = min(c_lo + 2, w - 1);
+    float v[4][SOFTMAX ? CT : 1];                 // SOFTMAX: all classes of the 4 pixels stay in registers
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const size_t obase = (size_t)b * C * HW + (size_t)oy * W + ox;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       if (c < C) {
         const float* pl = xb + (size_t)c * hw;
-        const float top = tx.w0 * pl[o00] + tx.w1 * pl[o01];
-        const float bot = tx.w0 * pl[o10] + tx.w1 * pl[o11];
-        v[c] = ty.w0 * top + ty.w1 * bot;
-        mx = fmaxf(mx, v[c]);
+        float val[4];
+        if (narrow) {
+          const float t0 = pl[r0 + c_lo], t1 = pl[r0 + k1], t2 = pl[r0 + k2];
+          const float b0 = pl[r1 + c_lo], b1 = pl[r1 + k1], b2 = pl[r1 + k2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int d0 = tx[e].i0 - c_lo, d1 = tx[e].i1 - c_lo;
+            const float ta = d0 == 0 ? t0 : (d0 == 1 ? t1 : t2), tb = d1 == 0 ? t0 : (d1 == 1 ? t1 : t2);
+            const float ba = d0 == 0 ? b0 : (d0 == 1 ? b1 : b2), bb = d1 == 0 ? b0 : (d1 == 1 ? b1 : b2);
+            const float top = tx[e].w0 * ta + tx[e].w1 * tb;
+            const float bot = tx[e].w0 * ba + tx[e].w1 * bb;
+            val[e] = ty.w0 * top + ty.w1 * bot;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float top = tx[e].w0 * pl[r0 + tx[e].i0] + tx[e].w1 * pl[r0 + tx[e].i1];
+            const float bot = tx[e].w0 * pl[r1 + tx[e].i0] + tx[e].w1 * pl[r1 + tx[e].i1];
+            val[e] = ty.w0 * top + ty.w1 * bot;
+          }
+        }
+        if (SOFTMAX) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e][c] = val[e];
+            mx[e] = fmaxf(mx[e], val[e]);
+          }
+        } else {                                     // logits only: stream the class plane out, nothing kept
+          float* o = up + obase + (size_t)c * HW;
+          if (nx == 4) {
+            *reinterpret_cast<f32x4u*>(o) = f32x4u{val[0], val[1], val[2], val[3]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (e < nx) o[e] = val[e];
+          }
+        }
       }
     }
-    const size_t obase = (size_t)b * C * HW + p;
-    if (up) {
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-        if (c < C) up[obase + (size_t)c * HW] = v[c];
-    }
-    if (probs || csum) {
-      float den = 0.f;
+    if (SOFTMAX && up) {
 #pragma unroll
       for (int c = 0; c < CT; ++c)
         if (c < C) {
-          v[c] = expf(v[c] - mx);
-          den += v[c];
+          float* o = up + obase + (size_t)c * HW;
+          if (nx == 4) {
+            *reinterpret_cast<f32x4u*>(o) = f32x4u{v[0][c], v[1][c], v[2][c], v[3][c]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (e < nx) o[e] = v[e][c];
+          }
         }
-      const float inv = 1.f / den;
-      const bool ign = ignore && ignore[(size_t)b * HW + p];
+    }
+    if (SOFTMAX && (probs || csum)) {
+      float inv[4];
+      bool ign[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float den = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          if (c < C) {
+            v[e][c] = expf(v[e][c] - mx[e]);
+            den += v[e][c];
+          }
+        inv[e] = 1.f / den;
+        ign[e] = ignore && e < nx && ignore[(size_t)b * HW + (size_t)oy * W + ox + e];
+      }
 #pragma unroll
       for (int c = 0; c < CT; ++c)
         if (c < C) {
-          const float pr = v[c] * inv;
-          acc[c] += pr;
-          if (probs) probs[obase + (size_t)c * HW] = ign ? 0.f : pr;
+          float pr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pr[e] = v[e][c] * inv[e];
+            if (e < nx) acc[c] += pr[e];
+            if (ign[e]) pr[e] = 0.f;
+          }
+          if (probs) {
+            float* o = probs + obase + (size_t)c * HW;
+            if (nx == 4) {
+              *reinterpret_cast<f32x4u*>(o) = f32x4u{pr[0], pr[1], pr[2], pr[3]};
+            } else {
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                if (e < nx) o[e] = pr[e];
+            }
+          }
         }
     }
   }
   if (csum) {
-    // per-thread partials (a few pixels each) -> LDS float atomics -> one double atomic per class and block
+    // per-thread partials -> wave sums (shuffles) -> one LDS atomic per wave and class -> one double atomic per block
 #pragma unroll
     for (int c = 0; c < CT; ++c)
-      if (c < C) atomicAdd(&s_sum[c], acc[c]);
+      if (c < C) {
+        const float ws = wave_sum(acc[c]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum[c], ws);
+      }
     __syncthreads();
     if (threadIdx.x < C) atomicAdd(&csum[threadIdx.x], (double)s_sum[threadIdx.x]);
   }
@@ -281,6 +360,141 @@ __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, cons
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
   if (per_class && threadIdx.x < C && s_pc[threadIdx.x] != 0.f) atomicAdd(&per_class[threadIdx.x], (double)s_pc[threadIdx.x]);
+}
+
+// ---- cross-entropy backward straight into the low-resolution gradient (K15 -> K9^T) ------------------------------
+// The loss is a function of logits_up = U(logits) with U the bilinear (ac=True) upsampling; its gradient w.r.t. the
+// stride-8 logits is U^T applied to the per-pixel d loss / d logits_up.  The two-kernel path wrote that full-resolution
+// tensor (359.5 MB for 8 crops) and read it back; here one block per high-res row (b, y) keeps it in LDS:
+//   phase 1  lanes along x (coalesced class-plane reads): softmax + the ce_loss weights -> d[c][x] in LDS,
+//   phase 2  x-reduction with the horizontal tap weights -> tmp[(b,c)][y][j]   (same weights, same summation order as
+//            upsample_bwd_x, so the result is the two-kernel path's bit for bit),
+// and upsample_bwd_y finishes with the vertical taps.  LDS index x + x/8 spreads the stride-8 phase-2 reads over all banks.
+__host__ __device__ __forceinline__ int ce_lds_index(int x) { return x + (x >> 3); }
+
+template <int CT>
+__global__ __launch_bounds__(kHB) void ce_bwd_rows(const float* __restrict__ xup, const int64_t* __restrict__ y,
+                                                  const float* __restrict__ cw, const float* __restrict__ conf, int B, int Crt,
+                                                  int H, int W, int w, float sw, int mode, const float* __restrict__ gscale,
+                                                  float* __restrict__ tmp) {
+  extern __shared__ float s_d[];                      // [C][pitch]
+  const int C = CT < kMaxC ? CT : Crt;
+  const int pitch = ce_lds_index(W - 1) + 2;
+  const int b = blockIdx.x / H, oy = blockIdx.x - b * H;
+  const int HW = H * W;
+  const float gs = gscale ? gscale[0] : 1.f;
+  const float norm = mode == 1 ? 1.f / ((float)B * (float)B * (float)HW) : 1.f / ((float)B * (float)HW);
+  // phase 1: four consecutive pixels per thread -- every class plane is ONE (4-byte aligned) dwordx4 load and all CT of
+  // them are in flight together (compile-time class count: no per-class predicate between the loads)
+  for (int ox = threadIdx.x * 4; ox < W; ox += kHB * 4) {
+    const int nx = min(4, W - ox);
+    const int p = oy * W + ox;
+    const size_t base = (size_t)b * C * HW + p;
+    f32x4u v[CT];
+    if (nx == 4) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < C) v[c] = *reinterpret_cast<const f32x4u*>(xup + base + (size_t)c * HW);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < C) {
+          v[c] = f32x4u{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+            if (e < nx) v[c][e] = xup[base + (size_t)c * HW + e];
+        }
+    }
+    float cs[4] = {1.f, 1.f, 1.f, 1.f};
+    if (mode == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[e] = 0.f;
+      if (nx == 4) {
+#pragma unroll 8
+        for (int bb = 0; bb < B; ++bb) {
+          const f32x4u cv = *reinterpret_cast<const f32x4u*>(conf + (size_t)bb * HW + p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cs[e] += cv[e];
+        }
+      } else {
+        for (int bb = 0; bb < B; ++bb) {
+          const float* cp = conf + (size_t)bb * HW + p;
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+            if (e < nx) cs[e] += cp[e];
+        }
+      }
+    }
+    int64_t lab[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lab[e] = e < nx ? y[(size_t)b * HW + p + e] : (int64_t)-1;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], v[c][e]);
+      }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[c][e] = expf(v[c][e] - mx[e]);
+          den[e] += v[c][e];
+        }
+      }
+    float k[4], gw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool valid = lab[e] >= 0 && lab[e] < C;
+      const float wgt = valid ? (cw ? cw[lab[e]] : 1.f) : 0.f;
+      const float gpw = cs[e] * norm * gs;
+      gw[e] = gpw * wgt;
+      k[e] = gw[e] / den[e];
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nx) s_d[c * pitch + ce_lds_index(ox + e)] = k[e] * v[c][e] - ((c == lab[e]) ? gw[e] : 0.f);
+      }
+  }
+  __syncthreads();
+  // phase 2: thread -> (column j, class group).  The tap weights of column j are computed once (registers) and reused
+  // for every class of the group; the sum runs over ascending x like upsample_bwd_x does.
+  constexpr int kMaxSpan = 24;                           // 2/scale + 3 taps: covers up-factors to 10
+  const int groups = max(1, min(C, kHB / max(w, 1)));
+  for (int o = threadIdx.x; o < w * groups; o += kHB) {
+    const int j = o % w, g0 = o / w;
+    int lo, hi;
+    src_range(j, sw, W, lo, hi);
+    const int n = hi - lo + 1;
+    if (n <= kMaxSpan) {
+      float wt[kMaxSpan];
+      int li[kMaxSpan];
+#pragma unroll
+      for (int i = 0; i < kMaxSpan; ++i) {
+        wt[i] = i < n ? weight_to(lo + i, sw, w, j) : 0.f;
+        li[i] = ce_lds_index(min(lo + i, W - 1));
+      }
+      for (int c = g0; c < C; c += groups) {
+        const float* row = s_d + c * pitch;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxSpan; ++i)
+          if (i < n) acc += wt[i] * row[li[i]];
+        tmp[((size_t)(b * C + c) * H + oy) * w + j] = acc;
+      }
+    } else {
+      for (int c = g0; c < C; c += groups) {
+        float acc = 0.f;
+        for (int xx = lo; xx <= hi; ++xx) acc += weight_to(xx, sw, w, j) * s_d[c * pitch + ce_lds_index(xx)];
+        tmp[((size_t)(b * C + c) * H + oy) * w + j] = acc;
+      }
+    }
+  }
 }
 
 __global__ void ce_finish(const double* __restrict__ partial, int n, float* __restrict__ loss,
@@ -483,13 +697,19 @@ extern "C" int dasac_upsample_softmax(const float* logits, int B, int C, int h, 
   DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && h > 0 && w > 0 && H > 0 && W > 0, "upsample_softmax: bad shape");
   hipStream_t s = as_stream(stream);
   if (class_sums) DASAC_HIP(hipMemsetAsync(class_sums, 0, C * sizeof(double), s));
-  const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
-  if (C == 19)
-    hipLaunchKernelGGL(upsample_softmax<19>, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H),
-                       ac_scale(w, W), ignore, up, probs, class_sums, per);
-  else
-    hipLaunchKernelGGL(upsample_softmax<kMaxC>, dim3(per * B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H),
-                       ac_scale(w, W), ignore, up, probs, class_sums, per);
+  const int64_t items = (int64_t)B * H * ((W + 3) / 4);
+  const bool softmax = probs || class_sums;
+  // softmax path: a few items per thread so that the class-sum reduction at the end is amortised
+  const int grid = stream_grid(items, kHB, softmax ? kNumCu * 4 : kNumCu * 16);
+#define DASAC_UPS(CT, SM)                                                                                              \
+  hipLaunchKernelGGL((upsample_softmax<CT, SM>), dim3(grid), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), \
+                     ac_scale(w, W), ignore, up, probs, class_sums, items)
+  if (C == 19) {
+    if (softmax) DASAC_UPS(19, true); else DASAC_UPS(19, false);
+  } else {
+    if (softmax) DASAC_UPS(kMaxC, true); else DASAC_UPS(kMaxC, false);
+  }
+#undef DASAC_UPS
   DASAC_CHECK_LAUNCH("upsample_softmax");
   return DASAC_OK;
 }
@@ -548,6 +768,39 @@ extern "C" int dasac_ce_loss(const float* logits, const int64_t* labels, const f
   DASAC_CHECK_LAUNCH("ce_loss");
   hipLaunchKernelGGL(ce_finish, dim3(1), dim3(64), 0, s, partial, blocks, loss, pc, per_class, C, 1.0 / ((double)HW * B));
   DASAC_CHECK_LAUNCH("ce_finish");
+  return DASAC_OK;
+}
+
+extern "C" size_t dasac_ce_loss_bwd_low_workspace(int B, int C, int H, int w) { return (size_t)B * C * H * w * sizeof(float); }
+
+extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labels, const float* class_weight, const float* conf,
+                                     int B, int C, int H, int W, int h, int w, int mode, const float* gscale, float* grad_low,
+                                     void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  DASAC_REQUIRE(logits_up && labels && grad_low && workspace, "ce_loss_bwd_low: null pointer");
+  DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && H > 0 && W > 0 && h > 0 && w > 0 && (int64_t)H * W < (1ll << 31) &&
+                    (mode == 0 || (mode == 1 && conf)),
+                "ce_loss_bwd_low: bad arguments");
+  if (ws_bytes < dasac_ce_loss_bwd_low_workspace(B, C, H, w)) return fail(DASAC_EWORKSPACE, "ce_loss_bwd_low: workspace too small");
+  const size_t lds = (size_t)C * (ce_lds_index(W - 1) + 2) * sizeof(float);
+  DASAC_REQUIRE(lds <= 160 * 1024, "ce_loss_bwd_low: a row of C x W gradients does not fit LDS");
+  hipStream_t s = as_stream(stream);
+  float* tmp = reinterpret_cast<float*>(workspace);
+  static std::atomic<int> lds_limit{64 * 1024};          // raise the kernel's dynamic-LDS limit once, not per launch
+  if ((int)lds > lds_limit.load(std::memory_order_relaxed)) {
+    DASAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_rows<19>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DASAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_rows<kMaxC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    lds_limit.store(160 * 1024, std::memory_order_relaxed);
+  }
+  if (C == 19)
+    hipLaunchKernelGGL(ce_bwd_rows<19>, dim3(B * H), dim3(kHB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
+                       ac_scale(w, W), mode, gscale, tmp);
+  else
+    hipLaunchKernelGGL(ce_bwd_rows<kMaxC>, dim3(B * H), dim3(kHB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
+                       ac_scale(w, W), mode, gscale, tmp);
+  DASAC_CHECK_LAUNCH("ce_bwd_rows");
+  const int64_t t2 = (int64_t)B * C * h * w;
+  hipLaunchKernelGGL(upsample_bwd_y, dim3(stream_grid(t2, kHB)), dim3(kHB), 0, s, tmp, H, h, w, ac_scale(h, H), nullptr, grad_low, t2);
+  DASAC_CHECK_LAUNCH("upsample_bwd_y");
   return DASAC_OK;
 }
 

@@ -84,30 +84,47 @@ __global__ __launch_bounds__(256) void maxpool_fwd(const float* __restrict__ x, 
 // dx[ih,iw] = sum over windows o containing (ih,iw) with argmax(o) == this position of dy(o)
 // relu_mask: additionally require y(o) > 0 -- the pooled tensor is ReLU output, so this is exactly
 // the ReLU backward of the producer folded in (no need to keep the un-pooled activation).
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Four consecutive input pixels of one row per thread: the (at most 2 x 3 for the 3x3/2 stem pool) windows that can
+// have picked any of them are read ONCE (argmax code, pooled value, gradient) and each routes its gradient to the
+// pixel its code names -- a scatter inside the thread's registers, no atomics; one dwordx4 store.  32-bit index math.
 __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                    const uint8_t* __restrict__ arg, int H, int W, int OH, int OW, int k,
-                                                   int s, int pad, int relu_mask, float* __restrict__ dx, int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int iw = (int)(i % W);
-    const int64_t r = i / W;
-    const int ih = (int)(r % H);
-    const int64_t plane = r / H;
-    const size_t ob = (size_t)plane * OH * OW;
-    // windows: oh*s - pad <= ih <= oh*s - pad + k - 1
-    int oh_lo = (ih + pad - k + 1 + s - 1) / s, oh_hi = (ih + pad) / s;
-    int ow_lo = (iw + pad - k + 1 + s - 1) / s, ow_hi = (iw + pad) / s;
+                                                   int s, int pad, int relu_mask, float* __restrict__ dx, int items) {
+  const int Wq = (W + 3) >> 2;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int q = it % Wq, row = it / Wq;            // row = plane*H + ih
+    const int ih = row % H, plane = row / H;
+    const int iw0 = q * 4, nx = min(4, W - iw0);
+    // windows: oh*s - pad <= ih <= oh*s - pad + k - 1, same for the columns iw0 .. iw0+3
+    int oh_lo = (ih + pad - k + 1 + s - 1) / s, oh_hi = min((ih + pad) / s, OH - 1);
+    int ow_lo = (iw0 + pad - k + 1 + s - 1) / s, ow_hi = min((iw0 + nx - 1 + pad) / s, OW - 1);
     if (ih + pad - k + 1 < 0) oh_lo = 0;
-    if (iw + pad - k + 1 < 0) ow_lo = 0;
-    if (oh_hi > OH - 1) oh_hi = OH - 1;
-    if (ow_hi > OW - 1) ow_hi = OW - 1;
-    float g = 0.f;
+    if (iw0 + pad - k + 1 < 0) ow_lo = 0;
+    const size_t ob = (size_t)plane * OH * OW;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
     for (int oh = oh_lo; oh <= oh_hi; ++oh)
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        const int code = (ih - (oh * s - pad)) * k + (iw - (ow * s - pad));
         const size_t o = ob + (size_t)oh * OW + ow;
-        if (arg[o] == code && (!relu_mask || y[o] > 0.f)) g += dy[o];
+        const int code = arg[o];
+        const int r = oh * s - pad + code / k, c = ow * s - pad + code % k - iw0;
+        if (r == ih && (unsigned)c < 4u && (!relu_mask || y[o] > 0.f)) {
+          const float d = dy[o];
+          g[0] += c == 0 ? d : 0.f;
+          g[1] += c == 1 ? d : 0.f;
+          g[2] += c == 2 ? d : 0.f;
+          g[3] += c == 3 ? d : 0.f;
+        }
       }
-    dx[i] = g;
+    float* out = dx + (size_t)row * W + iw0;
+    if (nx == 4) {
+      *reinterpret_cast<f32x4u*>(out) = f32x4u{g[0], g[1], g[2], g[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (e < nx) out[e] = g[e];
+    }
   }
 }
 
@@ -255,9 +272,10 @@ extern "C" int dasac_maxpool_fwd(const float* x, int planes, int H, int W, int O
 extern "C" int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t* argmax, int planes, int H, int W, int OH,
                                  int OW, int k, int s, int pad, int relu_mask, float* dx, dasac_stream_t stream) {
   DASAC_REQUIRE(dy && y && argmax && dx && planes > 0, "maxpool_bwd: bad arguments");
-  const int64_t total = (int64_t)planes * H * W;
-  hipLaunchKernelGGL(maxpool_bwd, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), dy, y, argmax, H, W, OH, OW, k,
-                     s, pad, relu_mask, dx, total);
+  const int64_t items = (int64_t)planes * H * ((W + 3) / 4);
+  DASAC_REQUIRE(items < (1ll << 31) && k >= 1 && s >= 1, "maxpool_bwd: tensor too large");
+  hipLaunchKernelGGL(maxpool_bwd, dim3(stream_grid(items, 256)), dim3(256), 0, as_stream(stream), dy, y, argmax, H, W, OH, OW, k,
+                     s, pad, relu_mask, dx, (int)items);
   DASAC_CHECK_LAUNCH("maxpool_bwd");
   return DASAC_OK;
 }

@@ -481,8 +481,11 @@ class _Upsample(torch.autograd.Function):
 
 
 def upsample_bilinear(logits, size):
-    """F.interpolate(logits, size, mode='bilinear', align_corners=True) (deeplabv2.py:217)."""
-    return _Upsample.apply(logits, tuple(int(s) for s in size))
+    """F.interpolate(logits, size, mode='bilinear', align_corners=True) (deeplabv2.py:217).  The result remembers the
+    low-resolution tensor it came from, so that a loss on it can send its gradient straight there (`_CELossLow`)."""
+    up = _Upsample.apply(logits, tuple(int(s) for s in size))
+    up._dasac_low = logits
+    return up
 
 
 class _CELoss(torch.autograd.Function):
@@ -499,12 +502,37 @@ class _CELoss(torch.autograd.Function):
         return dl, None, None, None
 
 
+class _CELossLow(torch.autograd.Function):
+    """The same loss value as _CELoss, differentiated w.r.t. the LOW-resolution logits that `logits_up` was upsampled from:
+    backward is one pass over logits_up (dasac_ce_loss_bwd_low) -- the full-resolution gradient (359.5 MB at 8 x 769^2)
+    is never written or read back.  `logits_up` enters detached; its own autograd edge (for other consumers) is untouched."""
+
+    @staticmethod
+    def forward(ctx, logits_low, logits_up, labels, class_weight, conf):
+        loss, _, _ = ops.ce_loss(logits_up, labels, class_weight, conf)
+        ctx.save_for_backward(logits_up, labels, class_weight, conf)
+        ctx.low_hw = tuple(logits_low.shape[2:])
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits_up, labels, class_weight, conf = ctx.saved_tensors
+        return ops.ce_loss_bwd_low(logits_up, labels, ctx.low_hw, class_weight, conf, gscale=g.contiguous()), None, None, None, None
+
+
+def _ce(logits_up, labels, class_weight, conf):
+    low = getattr(logits_up, "_dasac_low", None)
+    if low is not None and low.requires_grad and torch.is_grad_enabled() and tuple(low.shape[:2]) == tuple(logits_up.shape[:2]):
+        return _CELossLow.apply(low, logits_up.detach(), labels, class_weight, conf)
+    return _CELoss.apply(logits_up, labels, class_weight, conf)
+
+
 def ce_mean_all_pixels(logits_up, labels):
     """criterion(logits_up, y).mean().view(1) with CrossEntropyLoss(ignore_index=255, reduction='none')
     (deeplabv2.py:223-224): the mean runs over ALL pixels, ignored ones included."""
-    return _CELoss.apply(logits_up, labels, None, None)
+    return _ce(logits_up, labels, None, None)
 
 
 def focal_ce(logits_up, labels, class_weight, conf=None):
     """sac.py:119-149 loss value ([1]); conf given -> `_focal_ce_conf` broadcast form."""
-    return _CELoss.apply(logits_up, labels, class_weight, conf)
+    return _ce(logits_up, labels, class_weight, conf)

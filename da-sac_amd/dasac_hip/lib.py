@@ -35,6 +35,8 @@ PROTOTYPES = {
     "dasac_upsample_bwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "dasac_ce_loss_workspace": (_sz, [_i, _i, _l]),
     "dasac_ce_loss": (_i, [_p, _p, _p, _p, _i, _i, _l, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "dasac_ce_loss_bwd_low_workspace": (_sz, [_i, _i, _i, _i]),
+    "dasac_ce_loss_bwd_low": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "dasac_warp_affine": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "dasac_warp_pool": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "dasac_warp_back": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),

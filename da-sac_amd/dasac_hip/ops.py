@@ -328,6 +328,21 @@ def ce_loss(logits_up, labels, class_weight=None, conf=None, want_grad=False, wa
     return loss, dl, pc
 
 
+def ce_loss_bwd_low(logits_up, labels, low_hw, class_weight=None, conf=None, gscale=None):
+    """d loss / d (low-resolution logits) of `ce_loss` composed with the bilinear upsampling, in one pass over logits_up."""
+    lib = L.load()
+    L.require_gpu(logits_up, labels, class_weight, conf, gscale)
+    logits_up, labels = _c(logits_up), _c(labels)
+    B, Cn, H, W = logits_up.shape
+    h, w = int(low_hw[0]), int(low_hw[1])
+    out = _f32((B, Cn, h, w), logits_up)
+    ws = L.workspace(lib.dasac_ce_loss_bwd_low_workspace(B, Cn, H, w), logits_up.device)
+    L.check(lib.dasac_ce_loss_bwd_low(logits_up.data_ptr(), labels.data_ptr(), L.ptr(class_weight), L.ptr(None if conf is None else _c(conf)),
+                                      B, Cn, H, W, h, w, 0 if conf is None else 1, L.ptr(gscale), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      L.stream_ptr()), "dasac_ce_loss_bwd_low")
+    return out
+
+
 def warp_affine(x, theta):
     lib = L.load()
     L.require_gpu(x, theta)

@@ -183,6 +183,13 @@ int dasac_ce_loss(const float* logits, const int64_t* labels, const float* class
                   const float* conf, int B, int C, int64_t HW, int mode, const float* gscale,
                   float* loss, float* dlogits, float* per_class, void* workspace, size_t ws_bytes,
                   dasac_stream_t stream);
+/* Gradient of dasac_ce_loss w.r.t. the LOW-resolution logits the upsampled ones came from (deeplabv2.py:217 then
+ * :223-224 / sac.py:119-149): grad_low [B,C,h,w] = gscale[0] * U^T (d loss / d logits_up) without materialising the
+ * full-resolution gradient (same arithmetic and summation order as dasac_ce_loss(dlogits) + dasac_upsample_bwd). */
+size_t dasac_ce_loss_bwd_low_workspace(int B, int C, int H, int w);
+int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labels, const float* class_weight, const float* conf,
+                          int B, int C, int H, int W, int h, int w, int mode, const float* gscale, float* grad_low,
+                          void* workspace, size_t ws_bytes, dasac_stream_t stream);
 /* Inference (infer_val.py:160-163 and the result writer's argmax + trainId->labelId mapping, :60-65):
  * labels[b,y,x] = lut[argmax_c softmax(bilinear_ac(logits))[b,c,y,x]] (lut null: the class index), optional
  * conf = the winning probability.  1 (+4) bytes written per output pixel. */

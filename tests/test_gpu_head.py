@@ -201,3 +201,54 @@ def test_full_size_head_properties():
     assert float((pooled - probs[:2]).abs().max()) < 1e-3
     back = ops.warp_back(pooled, mask, eye, 4)
     assert float((back - same).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("shape,mode", [((2, 19, 9, 13, 65, 97), 1), ((3, 19, 5, 7, 33, 49), 0), ((2, 19, 97, 97, 769, 769), 1),
+                                        ((1, 7, 4, 6, 8, 12), 1), ((2, 19, 64, 128, 512, 1024), 0)])
+def test_ce_backward_straight_into_the_low_resolution_gradient(shape, mode):
+    """dasac_ce_loss_bwd_low == dasac_ce_loss(dlogits) followed by dasac_upsample_bwd (the two-kernel path it replaces,
+    itself pinned by goldens g3 / g6) -- same weights, same summation order: bit for bit; and autograd through the
+    engine's loss functions takes the fused path whenever the loss sits on an upsampled tensor."""
+    from dasac_hip import ops
+    from dasac_hip import engine as E
+    B, C, h, w, Hh, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    low = (torch.randn(B, C, h, w, generator=g) * 2).cuda()
+    y = torch.randint(0, C, (B, Hh, W), generator=g)
+    y[torch.rand(B, Hh, W, generator=g) < 0.3] = 255
+    y = y.cuda()
+    conf = torch.rand(B, 1, Hh, W, generator=g).cuda() if mode else None
+    cw = torch.rand(C, generator=g).cuda()
+    gs = torch.tensor([0.7], device="cuda")
+    up, _, _ = ops.upsample_softmax(low, (Hh, W))
+    _, dl, _ = ops.ce_loss(up, y, cw, conf, want_grad=True, gscale=gs)
+    ref = ops.upsample_bwd(dl, (h, w))
+    got = ops.ce_loss_bwd_low(up, y, (h, w), cw, conf, gscale=gs)
+    assert torch.equal(got, ref)
+    # through autograd: loss(upsample(low)) backpropagates into `low` without a full-resolution gradient tensor
+    lo1 = low.clone().requires_grad_(True)
+    loss = E.focal_ce(E.upsample_bilinear(lo1, (Hh, W)), y, cw, conf)
+    assert type(loss.grad_fn).__name__ == "_CELossLowBackward"
+    (0.7 * loss).sum().backward()
+    assert rel_err(lo1.grad, ref) < 1e-6
+    lo2 = low.clone().requires_grad_(True)
+    up2 = E.upsample_bilinear(lo2, (Hh, W))
+    loss2 = E._CELoss.apply(up2, y, cw, conf)                # the unfused path stays available
+    (0.7 * loss2).sum().backward()
+    assert rel_err(lo2.grad, ref) < 1e-6 and rel_err(loss2, loss) < 1e-7
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 9, 13, 65, 97), (1, 19, 4, 6, 8, 12), (2, 19, 5, 5, 6, 7), (1, 5, 3, 4, 10, 3), (2, 19, 33, 33, 33, 35)])
+def test_upsample_softmax_four_pixels_per_thread_edges(shape):
+    """Row tails (W % 4 != 0), up-factors below 4 (more than three low-res columns under four pixels), factor 1."""
+    from dasac_hip import ops
+    B, C, h, w, Hh, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, C, h, w, generator=g) * 3
+    ign = torch.rand(B, Hh, W, generator=g) < 0.2
+    up, probs, sums = ops.upsample_softmax(x.cuda(), (Hh, W), ign.cuda(), want_probs=True, want_sums=True)
+    ref_up = H.upsample_bilinear_ac(x, Hh, W)
+    ref_p = torch.softmax(ref_up, 1)
+    assert rel_err(up, ref_up) < TOL
+    assert rel_err(sums, ref_p.sum((0, 2, 3))) < 1e-5
+    assert rel_err(probs, ref_p * (~ign)[:, None]) < TOL
