@@ -70,6 +70,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int b
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// agent-scope (sc1) 16-byte accesses for data handed from one workgroup to another inside a launch: an sc1 store is
+// written through to memory, an sc1 load does not hit a stale line of this XCD's L2 / this CU's L1 -- the per-XCD L2s
+// are not coherent with each other (MI355X_MICROARCH.md, inter-workgroup visibility).  With both sides sc1 the hand-off
+// needs no buffer_wbl2 / buffer_inv fences (1.7-6.5 us each), only the flag's own release/acquire ordering.
+constexpr int kAuxSc1 = 16;
+__device__ __forceinline__ f32x4 buf_f32x4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxSc1);
+  return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
 __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
@@ -325,24 +334,23 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
     if (STREAMK) {
       if (ks > 0) {
         // I hold the LAST K-steps of a tile that starts in the previous range: deposit and move on.
+        // partial layout [range][32x32 sub-tile][quarter][thread][4]: 16-byte stores, a wave writes 1 KB contiguous
         const int dst0 = my_range * (ACC_REGS * kThreads * 4);     // bytes; scalar
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rpart, (unsigned)t * 4u,
-                                                    dst0 + ((i * TN + j) * 16 + r) * kThreads * 4, 0);
+            for (int r4 = 0; r4 < 4; ++r4)
+              __builtin_amdgcn_raw_buffer_store_b128(
+                  u32x4{__float_as_uint(acc[i][j][4 * r4]), __float_as_uint(acc[i][j][4 * r4 + 1]), __float_as_uint(acc[i][j][4 * r4 + 2]),
+                        __float_as_uint(acc[i][j][4 * r4 + 3])},
+                  rpart, (unsigned)t * 16u, dst0 + ((i * TN + j) * 4 + r4) * kThreads * 16, kAuxSc1);
             asm volatile("" ::: "memory");
           }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's write-through stores have left
         __syncthreads();
-        if (t == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(&flags[my_range], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (t == 0) __hip_atomic_store(&flags[my_range], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (ke < KT) {
         // I hold the FIRST K-steps; the rest was deposited by the following range(s), each at the very start of
         // its work (a range shorter than a tile -- fewer tiles than workers -- makes several of them contribute).
@@ -361,7 +369,6 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins >= (1 << 26)) __builtin_trap();
               }
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
               // self-cleaning flags: a range deposits at most once per launch and this worker is its only consumer,
               // so the flag can go back to 0 right here -- the next launch on the stream finds the array zeroed and
               // no memset (an extra kernel + two launch gaps per conv) is needed
@@ -373,9 +380,13 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
+                f32x4 pv[4];                                   // one sub-tile of the deposit: four 16-byte loads in flight
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr)
-                  acc[i][j][rr] += buf_f32(rpart, (unsigned)t * 4u, src0 + ((i * TN + j) * 16 + rr) * kThreads * 4);
+                for (int r4 = 0; r4 < 4; ++r4) pv[r4] = buf_f32x4_sc1(rpart, (unsigned)t * 16u, src0 + ((i * TN + j) * 4 + r4) * kThreads * 16);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += pv[r4][e];
                 asm volatile("" ::: "memory");
               }
           }
