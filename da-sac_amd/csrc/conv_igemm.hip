@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
 // coalesced tile writes and the strided MFMA operand reads are bank-conflict free.
 // ------------------------------------------------------------------------------------------
 constexpr int kWgPix = 32;   // pixels per K-step
-constexpr int kWgPitch = 33;
+constexpr int kWgPitch = 36;   // row pitch (floats): 16-byte aligned rows, 16 consecutive rows x 4 dwords hit 64 distinct banks
 
 // FAST: Cx % BN == 0 (the 128 im2col rows of a block belong to ONE tap) and M % 8 == 0: one (dh, dw)
 // per block, the per-row part of both operand addresses is a scalar offset, the pixel position is
@@ -646,19 +646,23 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
           }
       }
     } else {
-    const float* a_base = &sA[0][(wm * WM + li) * kWgPitch + lh];
-    const float* b_base = &sB[0][(wn * WN + li) * kWgPitch + lh];
+    // one ds_read_b128 per operand feeds FOUR MFMAs: lane half lh holds pixels 8g + 4*lh + {0..3} of its row and MFMA e
+    // contracts the pixel pair {8g + e, 8g + 4 + e} (any pairing is valid as long as both operands agree)
+    const float* a_base = &sA[0][(wm * WM + li) * kWgPitch + 4 * lh];
+    const float* b_base = &sB[0][(wn * WN + li) * kWgPitch + 4 * lh];
 #pragma unroll
-    for (int kk = 0; kk < kWgPix / 2; ++kk) {
-      float a[TM], b[TN];
+    for (int gq = 0; gq < kWgPix / 8; ++gq) {
+      f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = a_base[i * 32 * kWgPitch + 2 * kk];
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * kWgPitch + 8 * gq);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = b_base[j * 32 * kWgPitch + 2 * kk];
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * kWgPitch + 8 * gq);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
     }
     __syncthreads();
