@@ -232,11 +232,13 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
       const int4 e = tab[(kt) * BK]; /* one tap per K-step: (koff, dh, dw, channel offset) */        \
       const int ih = ih0 + e.y, iw = iw0 + e.z;                                                      \
       const bool ok = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);               \
-      const unsigned voff = ok ? (unsigned)(pixbase + (e.x - e.w)) * 4u : kPoison;                   \
+      /* the K-step's tap and first channel plane ride in the per-lane offset (one VALU add); what is left for the */ \
+      /* scalar operand -- the row's plane within the step -- is loop invariant: no scalar arithmetic per load      */ \
+      const unsigned voff = ok ? (unsigned)(pixbase + e.x) * 4u : kPoison;                           \
       _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                          \
         const int row0 = X3 ? 8 * bq0 + 4 * r : 4 * (bq0 + r * B_Q_PASS);                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
-          rb[r][j] = buf_f32(rx, voff, (e.w + (row0 + j) * planeHW) * 4);                            \
+          rb[r][j] = buf_f32(rx, voff, (row0 + j) * planeHW * 4);                                    \
       }                                                                                              \
     } else {                                                                                         \
       int4 te[B_QUADS * 4]; /* all table rows of this K-step first: one batch of scalar loads */     \
