@@ -18,6 +18,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "da-sac_amd"))
 
+# stdout carries exactly ONE line (the JSON).  Libraries print banners on file descriptor 1 behind Python's back (RCCL:
+# "RCCL version : ..." at communicator teardown), so fd 1 itself is pointed at stderr for the whole run and the JSON
+# line is written to the saved descriptor at the very end.
+_JSON_FD = os.dup(1)
+os.dup2(2, 1)
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -41,28 +47,27 @@ def model_cfg(arch="deeplabv2_resnet101", baseline=False):
 
 
 def cpu_baseline(size):
-    """The CPU oracle (a port of the reference's path, pinned to it by tests/) timed on this host's cores on a
-    BOUNDED sample: 1/8 of a cfg-3 step (1 source crop fwd+bwd, 1 target crop student fwd+bwd, 1 teacher fwd +
-    head + SGD) at half the crop side, scaled by the pixel ratio (conv cost is linear in pixels)."""
+    """The CPU oracle (a port of the reference's path, pinned to it by tests/) timed on this host's cores on a BOUNDED
+    sample of the SAME workload at FULL resolution: 1/8 of a cfg-3 step -- one source crop and one target crop (L = 1)
+    student forward + backward, one teacher forward, the SAC head and the SGD step, all at size x size (no pixel-ratio
+    extrapolation).  images/sec = 1 source image per sample time, as the per-step metric counts source images only."""
     from oracle import nets_ref as N
     from oracle.step_ref import SacOracle, SgdOracle, sac_train_iteration
     import driver
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(avail, 32))           # ATen's CPU convs stop scaling (and oversubscribe badly) beyond this
     torch.set_num_threads(cores)
-    small = (size + 1) // 2
     m = SacOracle(N.resnet101_state(seed=0, randomize_bn=True, he_init=True, residual_gain=0.1, aspp_gain=6.0))
     opt = SgdOracle(m)
-    src, tgt = driver.synthetic_batches(1, 1, 1, (small, small), "cpu", seed=1)
+    src, tgt = driver.synthetic_batches(1, 1, 1, (size, size), "cpu", seed=1)
     m.running_conf.fill_(0.05)
     m.slow_init[0] = 1.0
     t0 = time.time()
     sac_train_iteration(m, opt, src, tgt, 1, update_teacher=False)
     dt = time.time() - t0
-    scale = float(size * size) / float(small * small)
-    return {"value": round(1.0 / (dt * scale), 5), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "1/8 of one cfg-3 step (1 source + 1 target crop student fwd+bwd, 1 teacher fwd, head, SGD) at "
-                      "{0}x{0} = {1:.1f} s on {2} threads, scaled x{3:.2f} (pixel ratio) to {4}x{4}".format(small, dt, cores, scale, size)}
+    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1/8 of one cfg-3 step at full resolution (1 source + 1 target crop {0}x{0}: student fwd+bwd each, 1 teacher fwd, "
+                      "SAC head, SGD) = {1:.1f} s on {2} threads; 1 source image per sample".format(size, dt, cores)}
 
 
 def main():
@@ -95,9 +100,15 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_ddp = world == 1 and os.environ.get("DASAC_BENCH_DDP") == "1"     # measure the DDP wrapper's own cost on one GPU
+    if world > 1 or force_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if force_ddp:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import models
     import driver
@@ -112,7 +123,7 @@ def main():
     if not baseline:
         net.running_conf.fill_(0.05)
     optim = driver.make_optimizer(net, cfg)
-    step_net = nn.parallel.DistributedDataParallel(net, device_ids=[local]) if world > 1 else net
+    step_net = nn.parallel.DistributedDataParallel(net, device_ids=[local]) if (world > 1 or force_ddp) else net
     src, tgt = driver.synthetic_batches(args.batch, args.groups, args.views, hw, dev, seed=rank)
     if arch != "deeplabv2_resnet101":
         driver.calibrate_classifier(net, src[0][:1])          # logits std ~3 whatever the backbone's feature scale
@@ -150,8 +161,18 @@ def main():
         return dt_, prof_, res
 
     def kernel_table(prof_):
-        return {k: {"tflops": round(v["flops"] / max(v["seconds"], 1e-12) / 1e12, 2), "ms_per_step": round(v["seconds"] / args.steps * 1e3, 2),
-                    "launches_per_step": v["launches"] // args.steps} for k, v in prof_.items()}
+        """GEMM kernels: achieved TFLOP/s; streaming kernels: achieved TB/s of ALGORITHMIC bytes (each operand once)."""
+        out_ = {}
+        for k, v in prof_.items():
+            sec = max(v["seconds"], 1e-12)
+            row = {"ms_per_step": round(v["seconds"] / args.steps * 1e3, 3), "launches_per_step": v["launches"] // args.steps}
+            if v["flops"] > 0:
+                row["tflops"] = round(v["flops"] / sec / 1e12, 2)
+            if v.get("bytes", 0) > 0:
+                row["algorithmic_TB_per_s"] = round(v["bytes"] / sec / 1e12, 3)
+                row["algorithmic_MB_per_launch"] = round(v["bytes"] / max(v["launches"], 1) / 1e6, 1)
+            out_[k] = row
+        return out_
 
     ops.set_precision(args.precision)
     dt, prof, out = measure(0, args.warmup)
@@ -200,6 +221,7 @@ def main():
                          "kernel": "dasac::" + dom_name + " (forward + data-gradient implicit GEMM, {})".format(
                              "fp32 MFMA" if args.precision == "fp32" else "3 bf16 MFMAs per fp32 product: peak = bf16 peak / 3"),
                          "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
+                         "algorithmic_MB_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1) / 1e6, 1),
                          "launches": dom["launches"], "avg_launch_ms": round(dom["seconds"] / max(dom["launches"], 1) * 1e3, 4)},
             "kernels": kernel_table(prof),
             "check": {"loss_ce": losses.get("loss_ce"), "self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"),
@@ -209,9 +231,8 @@ def main():
             line["alt"] = alt
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
             line["cpu_baseline"] = cpu_baseline(args.size)
-        sys.stdout = sys.__stdout__
-        print(json.dumps(line))
-    if world > 1:
+        os.write(_JSON_FD, (json.dumps(line) + "\n").encode())
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
 
 

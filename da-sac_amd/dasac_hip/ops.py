@@ -25,21 +25,23 @@ class _Profile:
         self.on = False
         torch.cuda.synchronize()
         out = {}
-        for name, flops, a, b, tag in self.records:
-            d = out.setdefault((name, tag) if by_shape else name, {"flops": 0.0, "seconds": 0.0, "launches": 0})
+        for name, flops, a, b, tag, nbytes in self.records:
+            d = out.setdefault((name, tag) if by_shape else name, {"flops": 0.0, "bytes": 0.0, "seconds": 0.0, "launches": 0})
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["seconds"] += a.elapsed_time(b) * 1e-3
             d["launches"] += 1
         self.records = []
         return out
 
-    def span(self, name, flops, tag=None):
-        return _Span(self, name, flops, tag) if self.on else _NULL
+    def span(self, name, flops, tag=None, nbytes=0.0):
+        """flops / nbytes: ALGORITHMIC work of the launch (2*M*N*K; every operand once)."""
+        return _Span(self, name, flops, tag, nbytes) if self.on else _NULL
 
 
 class _Span:
-    def __init__(self, prof, name, flops, tag):
-        self.prof, self.name, self.flops, self.tag = prof, name, flops, tag
+    def __init__(self, prof, name, flops, tag, nbytes=0.0):
+        self.prof, self.name, self.flops, self.tag, self.nbytes = prof, name, flops, tag, nbytes
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -48,7 +50,7 @@ class _Span:
     def __exit__(self, *exc):
         b = torch.cuda.Event(enable_timing=True)
         b.record()
-        self.prof.records.append((self.name, self.flops, self.a, b, self.tag))
+        self.prof.records.append((self.name, self.flops, self.a, b, self.tag, self.nbytes))
 
 
 class _Null:
@@ -77,9 +79,10 @@ def pseudo_labels(probs, ignore, upper, lower, disc=None, want_idx=False):
     ign = None if ignore is None else _c(ignore).view(torch.uint8)
     ws_bytes = lib.dasac_pseudo_labels_workspace(B, Cn, HW)
     ws = L.workspace(ws_bytes, probs.device)
-    L.check(lib.dasac_pseudo_labels(probs.data_ptr(), L.ptr(ign), L.ptr(disc), float(upper), float(lower), B, Cn, HW,
-                                    labels.data_ptr(), conf.data_ptr(), L.ptr(idx), ws.data_ptr(), ws.numel(),
-                                    L.stream_ptr()), "dasac_pseudo_labels")
+    with PROFILE.span("pseudo_labels", 0.0, None, probs.numel() * 4.0 + B * HW * (1 + 8 + 4 + (8 if want_idx else 0))):
+        L.check(lib.dasac_pseudo_labels(probs.data_ptr(), L.ptr(ign), L.ptr(disc), float(upper), float(lower), B, Cn, HW,
+                                        labels.data_ptr(), conf.data_ptr(), L.ptr(idx), ws.data_ptr(), ws.numel(),
+                                        L.stream_ptr()), "dasac_pseudo_labels")
     return labels, conf, idx
 
 
@@ -181,7 +184,9 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
 
     def launch(span, pix_begin, pix_count, schedule):
         n = pix_count if pix_count else Nb * OH * OW - pix_begin
-        with PROFILE.span(span, 2.0 * n * M * K, tag):
+        frac = n / float(Nb * OH * OW)
+        nbytes = 4.0 * (x.numel() * frac + packed.numel() + n * M * (1 + (res is not None) + (mask is not None)))
+        with PROFILE.span(span, 2.0 * n * M * K, tag, nbytes):
             L.check(fn(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
                        stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
                        L.ptr(mask), int(relu), pix_begin, pix_count, schedule, L.ptr(ws), 0 if ws is None else ws.numel(),
@@ -241,7 +246,8 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=No
     table = conv_table(spec, H, W, False, x.device) if table is None else table
     nbytes = lib.dasac_conv_wgrad_workspace(Nb, OH, OW, M, spec.K)
     ws = L.workspace(nbytes, x.device)
-    with PROFILE.span("conv_wgrad", 2.0 * Nb * OH * OW * M * spec.K, (M, spec.K, Nb * OH * OW, spec.stride, 1, False, False)):
+    with PROFILE.span("conv_wgrad", 2.0 * Nb * OH * OW * M * spec.K, (M, spec.K, Nb * OH * OW, spec.stride, 1, False, False),
+                      4.0 * (dz.numel() + x.numel() + M * spec.K)):
         fn = lib.dasac_conv_wgrad_x3 if PRECISION == "bf16x3" else lib.dasac_conv_wgrad
         L.check(fn(_c(dz).data_ptr(), x.data_ptr(), table.data_ptr(), Nb, Cx, H, W, OH, OW, spec.stride, M,
                    spec.K, ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
@@ -275,8 +281,9 @@ def upsample_softmax(logits, size, ignore=None, want_up=True, want_probs=False, 
     probs = _f32((B, Cn, H, W), logits) if want_probs else None
     sums = torch.empty(Cn, dtype=torch.float64, device=logits.device) if want_sums else None
     ign = None if ignore is None else _c(ignore).view(torch.uint8)
-    L.check(lib.dasac_upsample_softmax(logits.data_ptr(), B, Cn, h, w, H, W, L.ptr(ign), L.ptr(up), L.ptr(probs),
-                                       L.ptr(sums), L.stream_ptr()), "dasac_upsample_softmax")
+    with PROFILE.span("upsample_softmax", 0.0, None, logits.numel() * 4.0 + B * Cn * H * W * 4.0 * (int(want_up) + int(want_probs)) + (B * H * W if ignore is not None else 0)):
+        L.check(lib.dasac_upsample_softmax(logits.data_ptr(), B, Cn, h, w, H, W, L.ptr(ign), L.ptr(up), L.ptr(probs),
+                                           L.ptr(sums), L.stream_ptr()), "dasac_upsample_softmax")
     return up, probs, sums
 
 
@@ -322,9 +329,10 @@ def ce_loss(logits_up, labels, class_weight=None, conf=None, want_grad=False, wa
     pc = _f32((Cn,), logits_up) if want_per_class else None
     nbytes = lib.dasac_ce_loss_workspace(B, Cn, HW)
     ws = L.workspace(nbytes, logits_up.device)
-    L.check(lib.dasac_ce_loss(logits_up.data_ptr(), labels.data_ptr(), L.ptr(class_weight), L.ptr(None if conf is None else _c(conf)),
-                              B, Cn, HW, 0 if conf is None else 1, L.ptr(gscale), loss.data_ptr(), L.ptr(dl), L.ptr(pc), ws.data_ptr(),
-                              ws.numel(), L.stream_ptr()), "dasac_ce_loss")
+    with PROFILE.span("ce_loss", 0.0, None, logits_up.numel() * 4.0 * (2 if want_grad else 1) + B * HW * (8 + (4 if conf is not None else 0))):
+        L.check(lib.dasac_ce_loss(logits_up.data_ptr(), labels.data_ptr(), L.ptr(class_weight), L.ptr(None if conf is None else _c(conf)),
+                                  B, Cn, HW, 0 if conf is None else 1, L.ptr(gscale), loss.data_ptr(), L.ptr(dl), L.ptr(pc), ws.data_ptr(),
+                                  ws.numel(), L.stream_ptr()), "dasac_ce_loss")
     return loss, dl, pc
 
 
@@ -337,9 +345,10 @@ def ce_loss_bwd_low(logits_up, labels, low_hw, class_weight=None, conf=None, gsc
     h, w = int(low_hw[0]), int(low_hw[1])
     out = _f32((B, Cn, h, w), logits_up)
     ws = L.workspace(lib.dasac_ce_loss_bwd_low_workspace(B, Cn, H, w), logits_up.device)
-    L.check(lib.dasac_ce_loss_bwd_low(logits_up.data_ptr(), labels.data_ptr(), L.ptr(class_weight), L.ptr(None if conf is None else _c(conf)),
-                                      B, Cn, H, W, h, w, 0 if conf is None else 1, L.ptr(gscale), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                      L.stream_ptr()), "dasac_ce_loss_bwd_low")
+    with PROFILE.span("ce_loss_bwd_low", 0.0, None, logits_up.numel() * 4.0 + B * H * W * (8 + (4 if conf is not None else 0)) + out.numel() * 4.0):
+        L.check(lib.dasac_ce_loss_bwd_low(logits_up.data_ptr(), labels.data_ptr(), L.ptr(class_weight), L.ptr(None if conf is None else _c(conf)),
+                                          B, Cn, H, W, h, w, 0 if conf is None else 1, L.ptr(gscale), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          L.stream_ptr()), "dasac_ce_loss_bwd_low")
     return out
 
 
@@ -372,9 +381,10 @@ def warp_pool(probs, theta, theta_inv, T, mode="avg_pool", tolerance=0.1, want_a
     pooled = _f32((N, Cn, H, W), probs)
     mask = _f32((N, 1, H, W), probs)
     aligned = torch.empty_like(probs) if want_aligned else None
-    L.check(lib.dasac_warp_pool(probs.data_ptr(), L.ptr(theta), L.ptr(theta_inv), N, T, Cn, H, W, POOL_MODES[mode],
-                                float(tolerance), L.ptr(aligned), pooled.data_ptr(), mask.data_ptr(), L.stream_ptr()),
-            "dasac_warp_pool")
+    with PROFILE.span("warp_pool", 0.0, None, probs.numel() * 4.0 * (2 if want_aligned else 1) + pooled.numel() * 4.0 + mask.numel() * 4.0):
+        L.check(lib.dasac_warp_pool(probs.data_ptr(), L.ptr(theta), L.ptr(theta_inv), N, T, Cn, H, W, POOL_MODES[mode],
+                                    float(tolerance), L.ptr(aligned), pooled.data_ptr(), mask.data_ptr(), L.stream_ptr()),
+                "dasac_warp_pool")
     return pooled, mask, aligned
 
 
@@ -386,8 +396,9 @@ def warp_back(pooled, mask, theta_inv, views_per_group):
     B = theta_inv.shape[0]
     assert B == N * views_per_group
     out = _f32((B, Cn, H, W), pooled)
-    L.check(lib.dasac_warp_back(pooled.data_ptr(), mask.data_ptr(), theta_inv.data_ptr(), B, views_per_group, Cn, H, W,
-                                out.data_ptr(), L.stream_ptr()), "dasac_warp_back")
+    with PROFILE.span("warp_back", 0.0, None, (pooled.numel() + mask.numel() + out.numel()) * 4.0):
+        L.check(lib.dasac_warp_back(pooled.data_ptr(), mask.data_ptr(), theta_inv.data_ptr(), B, views_per_group, Cn, H, W,
+                                    out.data_ptr(), L.stream_ptr()), "dasac_warp_back")
     return out
 
 
@@ -489,8 +500,9 @@ def maxpool_fwd(x, k, s, p, ceil_mode):
     OH, OW = pool_out(H, k, s, p, ceil_mode), pool_out(W, k, s, p, ceil_mode)
     y = _f32((B, Cn, OH, OW), x)
     arg = torch.empty((B, Cn, OH, OW), dtype=torch.uint8, device=x.device)
-    L.check(lib.dasac_maxpool_fwd(x.data_ptr(), B * Cn, H, W, OH, OW, k, s, p, y.data_ptr(), arg.data_ptr(), L.stream_ptr()),
-            "dasac_maxpool_fwd")
+    with PROFILE.span("maxpool_fwd", 0.0, None, x.numel() * 4.0 + y.numel() * 5.0):
+        L.check(lib.dasac_maxpool_fwd(x.data_ptr(), B * Cn, H, W, OH, OW, k, s, p, y.data_ptr(), arg.data_ptr(), L.stream_ptr()),
+                "dasac_maxpool_fwd")
     return y, arg
 
 
@@ -501,8 +513,9 @@ def maxpool_bwd(dy, y, arg, in_hw, k, s, p, relu_mask):
     B, Cn, OH, OW = dy.shape
     H, W = in_hw
     dx = _f32((B, Cn, H, W), dy)
-    L.check(lib.dasac_maxpool_bwd(dy.data_ptr(), y.data_ptr(), arg.data_ptr(), B * Cn, H, W, OH, OW, k, s, p, int(relu_mask),
-                                  dx.data_ptr(), L.stream_ptr()), "dasac_maxpool_bwd")
+    with PROFILE.span("maxpool_bwd", 0.0, None, dx.numel() * 4.0 + dy.numel() * 9.0):
+        L.check(lib.dasac_maxpool_bwd(dy.data_ptr(), y.data_ptr(), arg.data_ptr(), B * Cn, H, W, OH, OW, k, s, p, int(relu_mask),
+                                      dx.data_ptr(), L.stream_ptr()), "dasac_maxpool_bwd")
     return dx
 
 

@@ -52,6 +52,25 @@ class SAC(SAC_Baseline):
         self.register_buffer("slow_init", torch.Tensor([False]))
         self._ema_plan = None
         self._class_vectors = None
+        self._exempt_frozen_bn_buffers_from_ddp_broadcast()
+
+    def _exempt_frozen_bn_buffers_from_ddp_broadcast(self):
+        """DistributedDataParallel(broadcast_buffers=True) (train.py:104) re-sends EVERY buffer from rank 0 before each
+        forward.  For `running_conf` / `slow_init` that is behaviour to keep (rank 0's class prior wins).
+        The running statistics of frozen BatchNorm layers -- all of the teacher's, and the student's in SAC mode -- never
+        diverge between ranks (nobody writes them; the teacher's move by the same EMA everywhere), so re-sending them
+        changes no value; it only bumps their version counters, which would make the engine re-fold every BN and re-pack
+        176 MB of scale-folded weights per network on every forward (measured: +17 ms per cfg-3 step).  DDP honours this
+        module attribute when it is constructed."""
+        import torch.nn as nn
+        frozen = set(id(m) for m in getattr(self.backbone, "bn_freeze", []))
+        names = []
+        for prefix, net in (("backbone", self.backbone), ("slow_net", self.slow_net)):
+            for mname, m in net.named_modules():
+                if isinstance(m, BaseNet._batchnorm) and (prefix == "slow_net" or id(m) in frozen):
+                    for bname, _ in m.named_buffers(recurse=False):
+                        names.append(".".join(x for x in (prefix, mname, bname) if x))
+        self._ddp_params_and_buffers_to_ignore = names
 
     def _get_op(self, name):
         op_name = "_{}".format(name)
