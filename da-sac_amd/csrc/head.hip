@@ -293,16 +293,20 @@ __global__ __launch_bounds__(kHB) void upsample_bwd_y(const float* __restrict__ 
 }
 
 // ---- cross entropy -------------------------------------------------------------------------
-// One thread per pixel, looping over the B images of that pixel (needed by the cross-batch product
+// Each thread loops over the B images of its pixels (needed by the cross-batch product
 // of sac.py:148):   loss = sum_hw pw(hw) * sum_b ce_b(hw),
 //   mode 0  plain mean (deeplabv2.py:224, sac.py:132):  pw = 1/(B*HW)
 //   mode 1  focal_ce_conf (sac.py:148):                 pw = sum_i conf_i(hw) / (B*B*HW)
 // ce_b = -cw[y]*log_softmax(x)[y], 0 where y == 255.  dlogits (optional) = pw * cw[y] * (softmax - onehot).
 // per_class (optional, [C] double): sum over pixels of ce scattered by label (ignored -> class 0, value 0).
+// Four consecutive pixels per thread (the [B,C,HW] layout is contiguous in the flattened pixel index): every class plane
+// is one 4-byte-aligned dwordx4 load and all CT of an image are in flight together.
+template <int CT>
 __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, const int64_t* __restrict__ y,
-                                               const float* __restrict__ cw, const float* __restrict__ conf, int B, int C,
+                                               const float* __restrict__ cw, const float* __restrict__ conf, int B, int Crt,
                                                int HW, int mode, const float* __restrict__ gscale, float* __restrict__ dx,
                                                double* __restrict__ partial, double* __restrict__ per_class) {
+  const int C = CT < kMaxC ? CT : Crt;
   double lsum = 0.0;
   __shared__ float s_pc[kMaxC];
   if (per_class) {
@@ -311,48 +315,98 @@ __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, cons
   }
   const float gs = gscale ? gscale[0] : 1.f;   // upstream gradient of the scalar loss (device side)
   const float norm = mode == 1 ? 1.f / ((float)B * (float)B * (float)HW) : 1.f / ((float)B * (float)HW);
-  for (int p = blockIdx.x * kHB + threadIdx.x; p < HW; p += gridDim.x * kHB) {
-    float cs = 1.f;
+  const int items = (HW + 3) >> 2;
+  for (int it = blockIdx.x * kHB + threadIdx.x; it < items; it += gridDim.x * kHB) {
+    const int p = it * 4, nx = min(4, HW - p);
+    float cs[4] = {1.f, 1.f, 1.f, 1.f};
     if (mode == 1) {
-      cs = 0.f;
-      for (int b = 0; b < B; ++b) cs += conf[(size_t)b * HW + p];
-    }
-    const float pw = cs * norm;
-    const float gpw = pw * gs;
-    float cesum = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const size_t base = (size_t)b * C * HW + p;
-      const int64_t lab = y[(size_t)b * HW + p];
-      float v[kMaxC];
-      float mx = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < kMaxC; ++c)
-        if (c < C) {
-          v[c] = x[base + (size_t)c * HW];
-          mx = fmaxf(mx, v[c]);
+      for (int e = 0; e < 4; ++e) cs[e] = 0.f;
+      for (int b = 0; b < B; ++b) {
+        if (nx == 4) {
+          const f32x4u cv = *reinterpret_cast<const f32x4u*>(conf + (size_t)b * HW + p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cs[e] += cv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+            if (e < nx) cs[e] += conf[(size_t)b * HW + p + e];
         }
-      float den = 0.f, xl = 0.f;
-#pragma unroll
-      for (int c = 0; c < kMaxC; ++c)
-        if (c < C) {
-          const float e = expf(v[c] - mx);
-          den += e;
-          if (c == lab) xl = v[c];
-          v[c] = e;
-        }
-      const bool valid = lab >= 0 && lab < C;   // 255 (ignore) and anything out of range carry no loss
-      const float wgt = valid ? (cw ? cw[lab] : 1.f) : 0.f;
-      const float ce = valid ? wgt * (logf(den) - (xl - mx)) : 0.f;
-      cesum += ce;
-      if (per_class && valid && ce != 0.f) atomicAdd(&s_pc[lab], ce);
-      if (dx) {
-        const float k = gpw * wgt / den;
-#pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
-          if (c < C) dx[base + (size_t)c * HW] = k * v[c] - ((c == lab) ? gpw * wgt : 0.f);
       }
     }
-    lsum += (double)pw * (double)cesum;
+    float pw[4], cesum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pw[e] = cs[e] * norm;
+    for (int b = 0; b < B; ++b) {
+      const size_t base = (size_t)b * C * HW + p;
+      f32x4u v[CT];
+      if (nx == 4) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          if (c < C) v[c] = *reinterpret_cast<const f32x4u*>(x + base + (size_t)c * HW);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          if (c < C) {
+            v[c] = f32x4u{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (e < nx) v[c][e] = x[base + (size_t)c * HW + e];
+          }
+      }
+      int64_t lab[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lab[e] = e < nx ? y[(size_t)b * HW + p + e] : (int64_t)-1;
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0.f, 0.f, 0.f, 0.f}, xl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], v[c][e]);
+        }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (c == lab[e]) xl[e] = v[c][e];
+            const float ex = expf(v[c][e] - mx[e]);
+            den[e] += ex;
+            v[c][e] = ex;
+          }
+        }
+      float k[4], gw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool valid = lab[e] >= 0 && lab[e] < C;   // 255 (ignore) and anything out of range carry no loss
+        const float wgt = valid ? (cw ? cw[lab[e]] : 1.f) : 0.f;
+        const float ce = valid ? wgt * (logf(den[e]) - (xl[e] - mx[e])) : 0.f;
+        cesum[e] += ce;
+        if (per_class && valid && ce != 0.f && e < nx) atomicAdd(&s_pc[lab[e]], ce);
+        gw[e] = pw[e] * gs * wgt;
+        k[e] = gw[e] / den[e];
+      }
+      if (dx) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          if (c < C) {
+            f32x4u d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = k[e] * v[c][e] - ((c == lab[e]) ? gw[e] : 0.f);
+            float* o = dx + base + (size_t)c * HW;
+            if (nx == 4) {
+              *reinterpret_cast<f32x4u*>(o) = d;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                if (e < nx) o[e] = d[e];
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < nx) lsum += (double)pw[e] * (double)cesum[e];
   }
   __shared__ double red[kHB / 64];
   lsum = wave_sum(lsum);
@@ -360,6 +414,15 @@ __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, cons
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
   if (per_class && threadIdx.x < C && s_pc[threadIdx.x] != 0.f) atomicAdd(&per_class[threadIdx.x], (double)s_pc[threadIdx.x]);
+}
+
+__global__ void ce_finish(const double* __restrict__ partial, int n, float* __restrict__ loss,
+                          double* __restrict__ per_class, float* __restrict__ per_class_out, int C, double pc_norm) {
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss[0] = (float)s;
+  if (per_class_out && threadIdx.x < C) per_class_out[threadIdx.x] = (float)(per_class[threadIdx.x] * pc_norm);
 }
 
 // ---- cross-entropy backward straight into the low-resolution gradient (K15 -> K9^T) ------------------------------
@@ -495,15 +558,6 @@ __global__ __launch_bounds__(kHB) void ce_bwd_rows(const float* __restrict__ xup
       }
     }
   }
-}
-
-__global__ void ce_finish(const double* __restrict__ partial, int n, float* __restrict__ loss,
-                          double* __restrict__ per_class, float* __restrict__ per_class_out, int C, double pc_norm) {
-  double s = 0;
-  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) loss[0] = (float)s;
-  if (per_class_out && threadIdx.x < C) per_class_out[threadIdx.x] = (float)(per_class[threadIdx.x] * pc_norm);
 }
 
 // ---- affine warps: affine_grid + grid_sample(bilinear, zeros, align_corners=False) -------------
@@ -746,7 +800,7 @@ extern "C" int dasac_upsample_bwd(const float* grad_up, int planes, int h, int w
   return DASAC_OK;
 }
 
-static int ce_blocks(int64_t HW) { return stream_grid(HW, kHB, kNumCu * 8); }
+static int ce_blocks(int64_t HW) { return stream_grid((HW + 3) / 4, kHB, kNumCu * 8); }
 
 extern "C" size_t dasac_ce_loss_workspace(int B, int C, int64_t HW) {
   return align_up((size_t)ce_blocks(HW) * sizeof(double), 256) + align_up((size_t)kMaxC * sizeof(double), 256);
@@ -763,8 +817,12 @@ extern "C" int dasac_ce_loss(const float* logits, const int64_t* labels, const f
   double* partial = reinterpret_cast<double*>(workspace);
   double* pc = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)blocks * sizeof(double), 256));
   if (per_class) DASAC_HIP(hipMemsetAsync(pc, 0, kMaxC * sizeof(double), s));
-  hipLaunchKernelGGL(ce_loss, dim3(blocks), dim3(kHB), 0, s, logits, labels, class_weight, conf, B, C, (int)HW, mode, gscale,
-                     dlogits, partial, per_class ? pc : nullptr);
+  if (C == 19)
+    hipLaunchKernelGGL(ce_loss<19>, dim3(blocks), dim3(kHB), 0, s, logits, labels, class_weight, conf, B, C, (int)HW, mode, gscale,
+                       dlogits, partial, per_class ? pc : nullptr);
+  else
+    hipLaunchKernelGGL(ce_loss<kMaxC>, dim3(blocks), dim3(kHB), 0, s, logits, labels, class_weight, conf, B, C, (int)HW, mode, gscale,
+                       dlogits, partial, per_class ? pc : nullptr);
   DASAC_CHECK_LAUNCH("ce_loss");
   hipLaunchKernelGGL(ce_finish, dim3(1), dim3(64), 0, s, partial, blocks, loss, pc, per_class, C, 1.0 / ((double)HW * B));
   DASAC_CHECK_LAUNCH("ce_finish");
