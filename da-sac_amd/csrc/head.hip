@@ -843,11 +843,16 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
   DASAC_REQUIRE(lds <= 160 * 1024, "ce_loss_bwd_low: a row of C x W gradients does not fit LDS");
   hipStream_t s = as_stream(stream);
   float* tmp = reinterpret_cast<float*>(workspace);
-  static std::atomic<int> lds_limit{64 * 1024};          // raise the kernel's dynamic-LDS limit once, not per launch
-  if ((int)lds > lds_limit.load(std::memory_order_relaxed)) {
-    DASAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_rows<19>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DASAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_rows<kMaxC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    lds_limit.store(160 * 1024, std::memory_order_relaxed);
+  if (lds > 64 * 1024) {                                 // raise the kernels' dynamic-LDS limit once per device, not per launch
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    DASAC_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+      DASAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_rows<19>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      DASAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ce_bwd_rows<kMaxC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised.fetch_or(bit, std::memory_order_relaxed);
+    }
   }
   if (C == 19)
     hipLaunchKernelGGL(ce_bwd_rows<19>, dim3(B * H), dim3(kHB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,

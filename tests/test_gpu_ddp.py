@@ -140,3 +140,31 @@ def test_ddp_two_ranks_average_gradients_like_a_manual_mean():
         ref, out = sd[k].cpu(), got[0][2][k]
         assert float((ref - out).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9, k
         assert not torch.equal(out, start["backbone." + k].cpu()), k          # the step did move it
+
+
+def test_ddp_buffer_broadcast_does_not_repack_frozen_networks():
+    """DistributedDataParallel re-sends every buffer before each forward; for frozen BN that would bump the running
+    statistics' version counters and make the engine re-fold / re-pack both networks on every forward (+17 ms per cfg-3
+    step before SAC exempted them).  Two forwards under DDP: the second must pack nothing."""
+    from dasac_hip import ops
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        cfg, net = _build()
+        ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+        import driver
+        src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=3)
+        calls = []
+        real = ops.conv_pack
+        ops.conv_pack = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                ddp(tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4], use_teacher=True, update_teacher=True, T=2)
+                first = len(calls)
+                ddp(tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4], use_teacher=True, update_teacher=False, T=2)
+        finally:
+            ops.conv_pack = real
+        assert first > 0 and len(calls) == first, (first, len(calls))
+    finally:
+        dist.destroy_process_group()

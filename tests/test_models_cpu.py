@@ -76,3 +76,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("oracle/", ""), os.path.join(dirpath, f)
+
+
+def test_sac_exempts_exactly_the_frozen_bn_buffers_from_ddp_broadcast():
+    """models/sac.py (ours): DDP must keep broadcasting `running_conf` / `slow_init` from rank 0 but not the
+    running statistics of frozen BN layers, whose re-send would only invalidate the engine's packed-weight caches."""
+    import torch.nn as nn
+    import models
+    from types import SimpleNamespace as NS
+    from oracle.step_ref import DEFAULT_CFG
+    net = models.get_model(NS(**dict(DEFAULT_CFG, INIT_MODEL="")), 0, num_classes=19,
+                           criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    ign, bufs = set(net._ddp_params_and_buffers_to_ignore), dict(net.named_buffers())
+    assert ign <= set(bufs) and set(bufs) - ign == {"running_conf", "slow_init"}
+    assert all(k.split(".")[-1] in ("running_mean", "running_var", "num_batches_tracked") for k in ign)
+    base = models.get_model(NS(**dict(DEFAULT_CFG, INIT_MODEL="", BASELINE=True)), 0, num_classes=19,
+                            criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    assert not hasattr(base, "_ddp_params_and_buffers_to_ignore")      # baseline mode trains its BN: everything stays broadcast
