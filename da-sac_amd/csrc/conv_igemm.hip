@@ -117,9 +117,11 @@ __device__ __forceinline__ void split_bf16(f32x4 v0, f32x4 v1, f32x4& heads, f32
 // contiguous ranges, one per worker, so every CU gets the same amount of matrix work no matter how the
 // tile count divides by the CU count (1178 tiles on 256 CUs would otherwise run 5 "rounds" for 4.6 of
 // work).  A tile cut by a range boundary is finished by the worker holding its FIRST K-steps (it reaches
-// them last); the other worker deposits its accumulators in `partial` as soon as it has them -- at the very start
-// of its range, before it waits for anything itself, so no co-residency of all workers is required -- and raises
-// a flag (agent-scope release/acquire, placement independent).
+// them last); the other worker deposits its accumulators in `partial` as soon as it has them -- the tile segment a
+// range starts with is the first thing it computes, before it waits for anything itself, so no co-residency of all
+// workers is required -- and raises a flag.  The hand-off is placement independent (the per-XCD L2s are not coherent):
+// deposits are written with agent-scope (sc1, write-through) 16-byte stores and read with sc1 loads, the flag is an
+// agent-scope atomic that its single consumer resets (self-cleaning: no memset between launches).
 template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3>
 __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
