@@ -1102,7 +1102,9 @@ static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM, int BNk = 128) {
   const int tiles = (Mpad / BM) * (Kpad / BNk);
   const int slots = kNumCu * 3;
   int max_splits = (Npix + 1023) / 1024;                    // at least 1024 pixels per split
-  if (max_splits > 64) max_splits = 64;
+  // few tiles x many pixels (layer1 / stem: 2 tiles, 298k..1.2M pixels): more splits, or 128 blocks would face 768 slots
+  const int cap = (tiles < 12 && Npix >= 200000) ? (slots + tiles - 1) / tiles : 64;   // measured: no gain at 97x97 resolution
+  if (max_splits > cap) max_splits = cap;
   if (max_splits < 1) max_splits = 1;
   int best = 1;
   double best_eff = 0.0;
