@@ -314,6 +314,10 @@ class Engine:
         acts, aux = saved["acts"], saved["aux"]
         grads = [None] * len(self.params)
         g = {self.plan.output: grad_out.contiguous()}
+        # the d-gamma dot terms of all frozen-BN convs accumulate into slices of ONE zero-filled vector (one fill kernel
+        # per backward pass instead of one per layer)
+        dot_pool, dot_used = None, 0
+        dot_total = sum(op.spec.cout for op in self.plan.ops if op.kind == "conv" and op.bn is not None and op.expanded is None)
         pending = list(self.consumers)
         pending[self.plan.output] = 0
 
@@ -385,7 +389,10 @@ class Engine:
                 sums, dot = None, None
                 if any(w_need) or want_bn:
                     if want_bn:
-                        dot = torch.zeros(spec.cout, dtype=torch.float32, device=dz.device)
+                        if dot_pool is None:
+                            dot_pool = torch.zeros(dot_total, dtype=torch.float32, device=dz.device)
+                        dot = dot_pool[dot_used:dot_used + spec.cout]
+                        dot_used += spec.cout
                     if want_bn or want_bias:      # channel sums ride along with the wgrad kernel
                         sums = torch.empty(spec.cout, dtype=torch.float32, device=dz.device)
                     dws = ops.conv_wgrad(spec, dz, xin, [c.weight.detach() for c in op.convs], scale=scale, dot=dot,
