@@ -64,6 +64,8 @@ PROTOTYPES = {
     "dasac_iou_counts": (_i, [_p, _p, _i, _i, _l, _i, _p, _p]),
     "dasac_make_views_table_ints": (_i, [_i, _i]),
     "dasac_make_views": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "dasac_view_photometric_workspace": (_sz, [_i, _i, _i]),
+    "dasac_view_photometric": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _sz, _p]),
     "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

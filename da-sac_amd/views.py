@@ -13,8 +13,12 @@ and nothing else crosses PCIe.  Parameter draws use python's `random` in the ref
 `random.Random` reproduces the reference's views exactly; the pixels are byte-exact with Pillow's fixed-point
 resampling (tables built below in double precision, like Resample.c / Geometry.c).
 
-Not covered (they act on `images1` only and need torchvision.ColorJitter / PIL GaussianBlur arithmetic):
-RandGaussianBlur, MaskRandJitter, MaskRandGreyscale -- frames1 == frames2 here.
+The student's frames (`images1`) additionally go through `tf_augm` (dataloader_target.py:116-123,292-296):
+    RandGaussianBlur     tf_target.py:331-349     PIL GaussianBlur(radius ~ U(.1, 2)) per view
+    MaskRandJitter       tf_target.py:365-390     with probability p torchvision ColorJitter (4 adjustments, random order)
+    MaskRandGreyscale    tf_target.py:351-363     with probability p greyscale
+on the u8 views, before ToTensor / Normalize / ApplyMask: `dasac_view_photometric`, byte-exact with Pillow's BoxBlur.c /
+Blend.c / Convert.c (the arithmetic torchvision's PIL backend delegates to).  The teacher's frames (`images2`) stay clean.
 """
 import math
 import random
@@ -90,6 +94,42 @@ def sample_views(rng, n_views, H, W, zoom_range=(0.5, 1.0), guided_hflip=True):
     return views
 
 
+def sample_photometric(rng, torch_gen, n_views, blur=(.1, 2.), jitter=0.4, jitter_p=0.5, grey_p=0.2):
+    """The draws of `tf_augm` in the reference's call order: RandGaussianBlur (tf_target.py:341-343), MaskRandJitter
+    (:382-385) and MaskRandGreyscale (:358-360) each loop over the views.  `rng`: random.Random; `torch_gen`: the
+    torch.Generator ColorJitter.get_params draws from (torchvision >= 0.8: randperm(4), then uniform brightness, contrast,
+    saturation in [max(0, 1-j), 1+j] and hue in [-min(.1, j), min(.1, j)]).  Defaults = configs/deeplabv2_resnet101_train.yaml.
+    Returns one dict per view: blur radius or None, jitter (order, factors) or None, grey flag."""
+    views = [dict(blur=None, jitter=None, grey=False) for _ in range(n_views)]
+    if blur is not None:
+        for v in views:
+            v["blur"] = rng.uniform(blur[0], blur[1])
+    if jitter > 0:
+        lo, hi, hue = max(0., 1. - jitter), 1. + jitter, min(0.1, jitter)
+        for v in views:
+            if rng.random() < jitter_p:
+                order = torch.randperm(4, generator=torch_gen).tolist()
+                fac = [float(torch.empty(1).uniform_(a, b, generator=torch_gen)) for a, b in ((lo, hi), (lo, hi), (lo, hi), (-hue, hue))]
+                v["jitter"] = (order, fac)
+    if grey_p > 0:
+        for v in views:
+            v["grey"] = grey_p > rng.random()
+    return views
+
+
+def photometric_params(views):
+    """float64 [L, DASAC_PHOTO_PARAMS] rows for dasac_view_photometric (layout: include/dasac_hip.h)."""
+    out = np.zeros((len(views), 12), dtype=np.float64)
+    for r, v in enumerate(views):
+        out[r, 0] = v["blur"] if v["blur"] is not None else 0.0
+        if v["jitter"] is not None:
+            out[r, 1] = 1.0
+            out[r, 2:6] = v["jitter"][0]
+            out[r, 6:10] = v["jitter"][1]
+        out[r, 10] = 1.0 if v["grey"] else 0.0
+    return out
+
+
 def view_tables(views, H, W):
     """int32 [L, dasac_make_views_table_ints(H, W)] rows for dasac_make_views (layout: include/dasac_hip.h)."""
     stride = L.load().dasac_make_views_table_ints(H, W)
@@ -116,18 +156,52 @@ class TargetViews:
     """Device-side view generator for one target crop.  `make` returns what the reference's loader yields for one
     image (dataloader_target.py:306): (frames1, gt, frames2, affine, affine_inv) with frames1 is frames2."""
 
-    def __init__(self, crop_hw, group_size, zoom_range=(0.5, 1.0), guided_hflip=True, seed=None, mean=MEAN, std=STD):
+    def __init__(self, crop_hw, group_size, zoom_range=(0.5, 1.0), guided_hflip=True, seed=None, mean=MEAN, std=STD,
+                 blur=None, jitter=0.0, jitter_p=0.5, grey_p=0.0):
+        """blur = (r0, r1) / jitter / grey_p switch the photometric augmentations of frames1 on (cfg.DATASET.RND_BLUR,
+        RND_JITTER, RND_GREYSCALE; all off by default like core/config.py:78-81 minus the blur)."""
         self.H, self.W = int(crop_hw[0]), int(crop_hw[1])
         self.L, self.zoom, self.guided_hflip = int(group_size), tuple(zoom_range), bool(guided_hflip)
         self.rng = random.Random(seed)
+        self.torch_gen = torch.Generator()
+        if seed is not None:
+            self.torch_gen.manual_seed(seed)
         self.mean = np.asarray(mean, dtype=np.float32)
         self.std = np.asarray(std, dtype=np.float32)
+        self.blur, self.jitter, self.jitter_p, self.grey_p = blur, float(jitter), float(jitter_p), float(grey_p)
+
+    @property
+    def photometric(self):
+        return self.blur is not None or self.jitter > 0 or self.grey_p > 0
 
     def sample(self):
         return sample_views(self.rng, self.L, self.H, self.W, self.zoom, self.guided_hflip)
 
-    def make(self, image_u8, label_u8, mask_u8=None, views=None, want_u8=False):
-        """image_u8 [3,H,W] uint8 cuda (planar), label_u8 [H,W] uint8, mask_u8 [H,W] uint8 or None (non-zero = padding)."""
+    def sample_photometric(self):
+        return sample_photometric(self.rng, self.torch_gen, self.L, self.blur, self.jitter, self.jitter_p, self.grey_p)
+
+    def augment(self, views_u8, gt, photo, want_u8=False):
+        """`tf_augm` + post transforms on the u8 views of `make(..., want_u8=True)`: frames1 f32 [L,3,H,W] (+ the bytes)."""
+        L.require_gpu(views_u8, gt)
+        lib = L.load()
+        nv, H, W = views_u8.shape[0], self.H, self.W
+        assert tuple(views_u8.shape) == (nv, 3, H, W) and views_u8.dtype == torch.uint8 and views_u8.is_contiguous()
+        assert gt is None or (tuple(gt.shape) == (nv, H, W) and gt.dtype == torch.int64 and gt.is_contiguous())
+        dev = views_u8.device
+        params = np.ascontiguousarray(photometric_params(photo))
+        frames = torch.empty((nv, 3, H, W), dtype=torch.float32, device=dev)
+        u8 = torch.empty((nv, 3, H, W), dtype=torch.uint8, device=dev) if want_u8 else None
+        nbytes = lib.dasac_view_photometric_workspace(H, W, nv)
+        ws = L.workspace(nbytes, dev)
+        L.check(lib.dasac_view_photometric(views_u8.data_ptr(), L.ptr(gt), H, W, nv, params.ctypes.data, self.mean.ctypes.data,
+                                           self.std.ctypes.data, -1, frames.data_ptr(), L.ptr(u8), ws.data_ptr(), nbytes,
+                                           L.stream_ptr()), "dasac_view_photometric")
+        return (frames, u8) if want_u8 else frames
+
+    def make(self, image_u8, label_u8, mask_u8=None, views=None, want_u8=False, photo=None):
+        """image_u8 [3,H,W] uint8 cuda (planar), label_u8 [H,W] uint8, mask_u8 [H,W] uint8 or None (non-zero = padding).
+        With photometric augmentations configured (or `photo` given) frames1 is the augmented student input, frames2 the
+        clean teacher input, like `images1` / `images2` of dataloader_target.py:292-306."""
         L.require_gpu(image_u8, label_u8, mask_u8)
         lib = L.load()
         views = self.sample() if views is None else views
@@ -139,11 +213,14 @@ class TargetViews:
         tables = torch.from_numpy(view_tables(views, H, W)).pin_memory().to(dev, non_blocking=True)
         frames = torch.empty((nv, 3, H, W), dtype=torch.float32, device=dev)
         gt = torch.empty((nv, H, W), dtype=torch.int64, device=dev)
-        u8 = torch.empty((nv, 3, H, W), dtype=torch.uint8, device=dev) if want_u8 else None
+        if photo is None and self.photometric:
+            photo = self.sample_photometric()
+        u8 = torch.empty((nv, 3, H, W), dtype=torch.uint8, device=dev) if (want_u8 or photo is not None) else None
         L.check(lib.dasac_make_views(image_u8.data_ptr(), label_u8.data_ptr(), L.ptr(mask_u8), H, W, nv, tables.data_ptr(),
                                      self.mean.ctypes.data, self.std.ctypes.data, -1, frames.data_ptr(), gt.data_ptr(), L.ptr(u8),
                                      L.stream_ptr()), "dasac_make_views")
         theta, theta_inv = driver.view_affines([tuple(v["affine"]) for v in views], H, W)
         theta, theta_inv = theta.to(dev, non_blocking=True), theta_inv.to(dev, non_blocking=True)
-        out = (frames, gt, frames, theta, theta_inv)
+        frames1 = frames if photo is None else self.augment(u8, gt, photo)
+        out = (frames1, gt, frames, theta, theta_inv)
         return out + (u8,) if want_u8 else out

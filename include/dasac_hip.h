@@ -293,6 +293,23 @@ int dasac_make_views(const uint8_t* image, const uint8_t* label, const uint8_t* 
                      const int32_t* tables, const float* mean3, const float* std3, int ignore_label, float* frames,
                      int64_t* gt, uint8_t* views_u8, dasac_stream_t stream);
 
+/* Photometric augmentations of the student's views (second half): `tf_augm` of DataTarget
+ * (datasets/dataloader_target.py:116-123,292-296) = RandGaussianBlur (datasets/tf_target.py:331-349), MaskRandJitter
+ * (:365-390, torchvision ColorJitter) and MaskRandGreyscale (:351-363) on the u8 views dasac_make_views emits, then
+ * ToTensorMask / Normalize / ApplyMask (:33-98) -> frames1.  Byte-exact with Pillow's BoxBlur.c / Blend.c / Convert.c.
+ * views_u8 u8 [L,3,H,W] (L <= 16); gt i64 [L,H,W] from dasac_make_views or NULL (pixels with gt == ignore_label are
+ * the padding: frame value 0).  `params`: HOST array of L rows of DASAC_PHOTO_PARAMS doubles:
+ *   [0] Gaussian radius (<= 0: no blur)        [1] colour jitter on/off
+ *   [2..5] order of the four adjustments (0 brightness, 1 contrast, 2 saturation, 3 hue)
+ *   [6..9] brightness, contrast, saturation, hue factors        [10] greyscale on/off        [11] reserved
+ * Outputs: frames f32 [L,3,H,W]; out_u8 (optional) the augmented bytes.  `workspace`: device scratch of
+ * dasac_view_photometric_workspace(H, W, L) bytes. */
+#define DASAC_PHOTO_PARAMS 12
+size_t dasac_view_photometric_workspace(int H, int W, int L);
+int dasac_view_photometric(const uint8_t* views_u8, const int64_t* gt, int H, int W, int L, const double* params,
+                           const float* mean3, const float* std3, int ignore_label, float* frames, uint8_t* out_u8,
+                           void* workspace, size_t ws_bytes, dasac_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

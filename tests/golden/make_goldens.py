@@ -494,9 +494,101 @@ def g12_views():
     save("g12_views", **rec)
 
 
+# ------------------------------------------------------------------------------------------------
+# G13: the photometric augmentations of the student's views through the reference's own classes
+# (datasets/tf_target.py: RandGaussianBlur :331-349, MaskRandJitter :365-390, MaskRandGreyscale :351-363) on PIL
+# images, python `random` and torch's global RNG seeded.  Blur and greyscale are Pillow end to end.  MaskRandJitter
+# delegates to torchvision.transforms.ColorJitter, and torchvision is ABSENT from this image (the reference pins no
+# version): `_ColorJitterStandIn` below restates its published control flow (torchvision >= 0.8: get_params draws
+# torch.randperm(4) and four torch uniforms; functional_pil applies PIL.ImageEnhance.{Brightness,Contrast,Color} and the
+# HSV hue shift) -- the pixel arithmetic inside it is the real Pillow's.  So this fixture pins blur / greyscale / the
+# ImageEnhance + HSV arithmetic and the reference's own draw order and probabilities; ColorJitter's internal draw order
+# is restated, not pinned.
+# ------------------------------------------------------------------------------------------------
+class _ColorJitterStandIn:
+    def __init__(self, brightness=0, contrast=0, saturation=0, hue=0):
+        self.brightness = [max(0., 1. - brightness), 1. + brightness] if brightness else None
+        self.contrast = [max(0., 1. - contrast), 1. + contrast] if contrast else None
+        self.saturation = [max(0., 1. - saturation), 1. + saturation] if saturation else None
+        self.hue = [-hue, hue] if hue else None
+        self.log = []
+
+    def __call__(self, img):
+        from PIL import Image, ImageEnhance
+        order = torch.randperm(4).tolist()
+        fac = [None if r is None else float(torch.empty(1).uniform_(r[0], r[1])) for r in (self.brightness, self.contrast, self.saturation, self.hue)]
+        self.log.append((order, fac))
+        for k in order:
+            if fac[k] is None:
+                continue
+            if k == 0:
+                img = ImageEnhance.Brightness(img).enhance(fac[k])
+            elif k == 1:
+                img = ImageEnhance.Contrast(img).enhance(fac[k])
+            elif k == 2:
+                img = ImageEnhance.Color(img).enhance(fac[k])
+            else:
+                h, s_, v = img.convert("HSV").split()
+                np_h = np.array(h, dtype=np.uint8)
+                with np.errstate(over="ignore"):
+                    np_h += np.int32(fac[k] * 255).astype(np.uint8)
+                img = Image.merge("HSV", (Image.fromarray(np_h, "L"), s_, v)).convert("RGB")
+        return img
+
+
+def g13_photometric():
+    import random
+    from PIL import Image
+    _install_tv_functional()
+    F_ = sys.modules["torchvision.transforms.functional"]
+
+    def to_grayscale(img, num_output_channels=1):          # torchvision functional_pil.to_grayscale
+        img = img.convert("L")
+        if num_output_channels == 3:
+            a = np.array(img, dtype=np.uint8)
+            img = Image.fromarray(np.dstack([a, a, a]), "RGB")
+        return img
+    F_.to_grayscale = to_grayscale
+    sys.modules["torchvision.transforms"].ColorJitter = _ColorJitterStandIn
+    import datasets.tf_target as tft
+    rec = {}
+    H, W, L = 48, 80, 4
+    cases = ((11, 0.4, 0.2), (12, 0.4, 0.9), (13, 0.5, 0.0), (14, 0.05, 0.5))      # seed, jitter, greyscale p
+    for case, (seed, jitter, grey_p) in enumerate(cases):
+        gen = np.random.RandomState(seed)
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = np.stack([(127 + 110 * np.sin(xx / (2.0 + c) + yy / (4.0 + c)) + gen.randint(-20, 21, (H, W))).clip(0, 255) for c in range(3)], -1).astype(np.uint8)
+        img[:6, :9] = (255, 0, 0)
+        img[-5:, -7:] = 128
+        images = [Image.fromarray(img) for _ in range(L)]
+        random.seed(2000 + seed)
+        torch.manual_seed(2000 + seed)
+        blur, jit, grey = tft.RandGaussianBlur(), tft.MaskRandJitter(jitter), tft.MaskRandGreyscale(grey_p)
+        state = random.getstate()
+        out, _, _ = tft.Compose([blur, jit, grey])(images, [None] * L, [None] * L)
+        t = "c%d_" % case
+        rec.update({t + "image": img, t + "seed": 2000 + seed, t + "jitter": jitter, t + "grey_p": grey_p,
+                    t + "out_u8": np.stack([np.array(im) for im in out])})
+        # the draws, replayed from the saved generator state in the classes' order, for the test's sampler to reproduce
+        random.setstate(state)
+        radii = [random.uniform(.1, 2.) for _ in range(L)]
+        hits = [random.random() < 0.5 for _ in range(L)]
+        greys = [grey_p > random.random() for _ in range(L)]
+        assert sum(hits) == len(jit.jitter.log)
+        rec[t + "radii"] = np.array(radii)
+        rec[t + "jitter_on"] = np.array(hits)
+        rec[t + "grey_on"] = np.array(greys)
+        rec[t + "jitter_order"] = np.array([o for o, _ in jit.jitter.log], dtype=np.int64).reshape(-1, 4)
+        rec[t + "jitter_factors"] = np.array([f for _, f in jit.jitter.log], dtype=np.float64).reshape(-1, 4)
+        print("case", case, "radii", np.round(radii, 3), "jitter", hits, "grey", greys)
+    rec["n_cases"] = len(cases)
+    save("g13_photometric", **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11", "g12"]
+    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11", "g12", "g13"]
     table = dict(g3=g3_bilinear, g4=g4_refine, g5=g5_pseudo_labels, g6=g6_losses, g7=g7_state_sequences,
-                 g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture, g11=g11_index_tables, g12=g12_views)
+                 g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture, g11=g11_index_tables, g12=g12_views,
+                 g13=g13_photometric)
     for w in which:
         table[w]()

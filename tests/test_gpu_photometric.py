@@ -1,0 +1,79 @@
+"""Photometric view augmentations on the device (da-sac_amd/views.py: TargetViews.augment -> dasac_view_photometric)
+against golden g13 -- outputs of the reference's RandGaussianBlur / MaskRandJitter / MaskRandGreyscale -- and against the
+Pillow-pinned oracle on fresh images.  Byte work: bit-exact; the normalised frames: torch.equal."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import photometric_ref as P
+from oracle import views_ref as V
+from test_photometric_cpu import _golden_views
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _planar(a):
+    return T(np.ascontiguousarray(a.transpose(0, 3, 1, 2)))
+
+
+def test_photometric_golden_g13_bit_exact(golden):
+    import views
+    g = golden("g13_photometric")
+    for case in range(int(g["n_cases"])):
+        t = "c%d_" % case
+        vs = _golden_views(g, case)
+        img = g[t + "image"]
+        H, W, _ = img.shape
+        tv = views.TargetViews((H, W), len(vs))
+        u8 = _planar(np.stack([img] * len(vs))).cuda()
+        frames, out = tv.augment(u8, None, vs, want_u8=True)
+        assert torch.equal(out.cpu(), _planar(g[t + "out_u8"])), case
+        ref_frames, _ = V.post_transform([(o, np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8)) for o in g[t + "out_u8"]], views.MEAN, views.STD)
+        assert torch.equal(frames.cpu(), ref_frames), case
+
+
+@pytest.mark.parametrize("hw,seed", [((37, 53), 1), ((64, 96), 2), ((512, 1024), 3), ((5, 3), 4)])
+def test_photometric_vs_oracle_fresh_images(hw, seed):
+    import views
+    H, W = hw
+    gen = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    L = 4
+    imgs = np.stack([np.stack([(127 + 100 * np.sin(xx / (3.0 + c + v) + yy / 6.0) + gen.randint(-30, 31, (H, W))).clip(0, 255) for c in range(3)], -1)
+                     for v in range(L)]).astype(np.uint8)
+    imgs[0, : H // 3] = gen.randint(0, 256, (H // 3, W, 3))                     # noise: every HSV sector, saturated bytes
+    gt = gen.randint(0, 19, (L, H, W)).astype(np.int64)
+    gt[:, :, : max(W // 8, 1)] = -1                                              # padding columns
+    tv = views.TargetViews(hw, L, seed=seed, blur=(.1, 2.), jitter=0.4, jitter_p=0.75, grey_p=0.3)
+    photo = tv.sample_photometric()
+    ref = P.sample_photometric(random.Random(seed), torch.Generator().manual_seed(seed), L, (.1, 2.), 0.4, 0.75, 0.3)
+    assert photo == ref
+    photo[1] = dict(blur=None, jitter=([1, 3, 0, 2], [1.4, 0.6, 1.0, 0.1]), grey=False)       # no blur, contrast first, alpha == 1
+    photo[2] = dict(blur=2.0, jitter=None, grey=True)
+    frames, out = tv.augment(_planar(imgs).cuda(), T(gt).cuda(), photo, want_u8=True)
+    want = np.stack([P.photometric_u8(imgs[v], photo[v]) for v in range(L)])
+    assert torch.equal(out.cpu(), _planar(want))
+    ref_frames, _ = V.post_transform([(want[v], np.zeros((H, W), np.uint8), (gt[v] == -1).astype(np.uint8)) for v in range(L)], views.MEAN, views.STD)
+    assert torch.equal(frames.cpu(), ref_frames)
+
+
+def test_make_returns_augmented_student_frames_and_clean_teacher_frames():
+    import views
+    H, W, seed = 64, 96, 9
+    gen = np.random.RandomState(seed)
+    img = gen.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    lab = gen.randint(0, 19, (H, W)).astype(np.uint8)
+    tv = views.TargetViews((H, W), 4, zoom_range=(0.5, 1.0), seed=seed, blur=(.1, 2.), jitter=0.4, grey_p=0.2)
+    vs, photo = tv.sample(), tv.sample_photometric()
+    f1, gt, f2, _, _, u8 = tv.make(T(np.ascontiguousarray(img.transpose(2, 0, 1))).cuda(), T(lab).cuda(), None, views=vs, want_u8=True, photo=photo)
+    ref_u8 = V.make_views_u8(img, lab, np.zeros((H, W), np.uint8), vs)
+    clean, ref_gt = V.post_transform(ref_u8, views.MEAN, views.STD)
+    aug = [(P.photometric_u8(o[0], p), o[1], o[2]) for o, p in zip(ref_u8, photo)]
+    student, _ = V.post_transform(aug, views.MEAN, views.STD)
+    assert torch.equal(f2.cpu(), clean) and torch.equal(gt.cpu(), ref_gt) and torch.equal(f1.cpu(), student)
+    assert not torch.equal(f1, f2)
+    with pytest.raises(Exception):
+        tv.augment(u8[:, :2], None, photo)
