@@ -52,27 +52,34 @@ __global__ __launch_bounds__(256) void channel_sums(const float* __restrict__ x,
 
 // ---- max pooling (deeplabv2.py:126 3x3/2 pad 1 ceil_mode; torchvision VGG 2x2/2) -------------------
 // forward also records the argmax position inside the window (kh*k + kw), first maximum wins.
-__global__ __launch_bounds__(256) void maxpool_fwd(const float* __restrict__ x, int H, int W, int OH, int OW, int k, int s,
-                                                   int pad, float* __restrict__ y, uint8_t* __restrict__ arg,
-                                                   int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int ow = (int)(i % OW);
-    const int64_t r = i / OW;
-    const int oh = (int)(r % OH);
-    const int64_t plane = r / OH;
-    const float* xp = x + plane * H * W;
+// KT / ST: compile-time window and stride (0 = take the runtime values): the 3x3/2 stem pool and the 2x2/2, 3x3/1 VGG pools
+// get unrolled windows and no integer division by a runtime value; all index math is 32-bit (total < 2^31, checked by the host).
+template <int KT, int ST>
+__global__ __launch_bounds__(256) void maxpool_fwd(const float* __restrict__ x, int H, int W, int OH, int OW, int k_rt, int s_rt,
+                                                   int pad, float* __restrict__ y, uint8_t* __restrict__ arg, int total) {
+  const int k = KT ? KT : k_rt, s = ST ? ST : s_rt;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int ow = i % OW, r = i / OW;
+    const int oh = r % OH, plane = r / OH;
+    const float* xp = x + (size_t)plane * H * W;
+    const int ih0 = oh * s - pad, iw0 = ow * s - pad;
     float best = -INFINITY;
     int code = 0;
-    for (int a = 0; a < k; ++a) {
-      const int ih = oh * s - pad + a;
-      if (ih < 0 || ih >= H) continue;
-      for (int b = 0; b < k; ++b) {
-        const int iw = ow * s - pad + b;
-        if (iw < 0 || iw >= W) continue;
-        const float v = xp[ih * W + iw];
-        if (v > best || v != v) {
-          best = v;
-          code = a * k + b;
+#pragma unroll
+    for (int a = 0; a < (KT ? KT : 15); ++a) {
+      if (!KT && a >= k) break;
+      const int ih = ih0 + a;
+      const bool rowok = (unsigned)ih < (unsigned)H;
+#pragma unroll
+      for (int b = 0; b < (KT ? KT : 15); ++b) {
+        if (!KT && b >= k) break;
+        const int iw = iw0 + b;
+        if (rowok && (unsigned)iw < (unsigned)W) {
+          const float v = xp[ih * W + iw];
+          if (v > best || v != v) {
+            best = v;
+            code = a * k + b;
+          }
         }
       }
     }
@@ -89,9 +96,11 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 // Four consecutive input pixels of one row per thread: the (at most 2 x 3 for the 3x3/2 stem pool) windows that can
 // have picked any of them are read ONCE (argmax code, pooled value, gradient) and each routes its gradient to the
 // pixel its code names -- a scatter inside the thread's registers, no atomics; one dwordx4 store.  32-bit index math.
+template <int KT, int ST>
 __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy, const float* __restrict__ y,
-                                                   const uint8_t* __restrict__ arg, int H, int W, int OH, int OW, int k,
-                                                   int s, int pad, int relu_mask, float* __restrict__ dx, int items) {
+                                                   const uint8_t* __restrict__ arg, int H, int W, int OH, int OW, int k_rt,
+                                                   int s_rt, int pad, int relu_mask, float* __restrict__ dx, int items) {
+  const int k = KT ? KT : k_rt, s = ST ? ST : s_rt;
   const int Wq = (W + 3) >> 2;
   for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
     const int q = it % Wq, row = it / Wq;            // row = plane*H + ih
@@ -263,8 +272,13 @@ extern "C" int dasac_maxpool_fwd(const float* x, int planes, int H, int W, int O
                                  uint8_t* argmax, dasac_stream_t stream) {
   DASAC_REQUIRE(x && y && argmax && planes > 0 && k > 0 && k <= 15 && s > 0, "maxpool_fwd: bad arguments");
   const int64_t total = (int64_t)planes * OH * OW;
-  hipLaunchKernelGGL(maxpool_fwd, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, H, W, OH, OW, k, s, pad, y,
-                     argmax, total);
+  DASAC_REQUIRE(total < (1ll << 31), "maxpool_fwd: tensor too large");
+  const dim3 grid(stream_grid(total, 256));
+  hipStream_t st = as_stream(stream);
+  if (k == 3 && s == 2) hipLaunchKernelGGL((maxpool_fwd<3, 2>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
+  else if (k == 2 && s == 2) hipLaunchKernelGGL((maxpool_fwd<2, 2>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
+  else if (k == 3 && s == 1) hipLaunchKernelGGL((maxpool_fwd<3, 1>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
+  else hipLaunchKernelGGL((maxpool_fwd<0, 0>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
   DASAC_CHECK_LAUNCH("maxpool_fwd");
   return DASAC_OK;
 }
@@ -274,8 +288,12 @@ extern "C" int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t*
   DASAC_REQUIRE(dy && y && argmax && dx && planes > 0, "maxpool_bwd: bad arguments");
   const int64_t items = (int64_t)planes * H * ((W + 3) / 4);
   DASAC_REQUIRE(items < (1ll << 31) && k >= 1 && s >= 1, "maxpool_bwd: tensor too large");
-  hipLaunchKernelGGL(maxpool_bwd, dim3(stream_grid(items, 256)), dim3(256), 0, as_stream(stream), dy, y, argmax, H, W, OH, OW, k,
-                     s, pad, relu_mask, dx, (int)items);
+  const dim3 grid(stream_grid(items, 256));
+  hipStream_t st = as_stream(stream);
+  if (k == 3 && s == 2) hipLaunchKernelGGL((maxpool_bwd<3, 2>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
+  else if (k == 2 && s == 2) hipLaunchKernelGGL((maxpool_bwd<2, 2>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
+  else if (k == 3 && s == 1) hipLaunchKernelGGL((maxpool_bwd<3, 1>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
+  else hipLaunchKernelGGL((maxpool_bwd<0, 0>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
   DASAC_CHECK_LAUNCH("maxpool_bwd");
   return DASAC_OK;
 }
