@@ -183,10 +183,14 @@ __global__ void ema_finish(const double* __restrict__ sq, int n, float* __restri
 
 // ---- torch.optim.SGD(momentum, dampening 0, no nesterov) over every parameter in one launch ---------
 // (base_trainer.py:63-66 builds it over the four groups of basenet.py:73-95; per-group lr / weight decay)
-//   d = g + wd*p ;  buf = first ? d : momentum*buf + d ;  p = p - lr*buf        (same op order as ATen)
+//   d = g (+ g2) + wd*p ;  buf = first ? d : momentum*buf + d ;  p = p - lr*buf        (same op order as ATen)
+// g2 (optional): a second gradient of the same parameter -- the source-pass gradient the driver set aside while the target
+// pass ran (train.py accumulates both into .grad: one `add_` launch per parameter, 320 per step; here the sum happens in
+// the update itself, g2 + g in AccumulateGrad's operand order, so the result is bit-identical).
 struct SgdTensor {
   float* p;
   const float* g;
+  const float* g2;
   float* buf;
   int64_t n;
   int64_t group;
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(256) void sgd_chunks(const SgdTensor* __restrict__ 
     if (i < t.n) {
       const float p = t.p[i];
       float d = t.g[i];
+      if (t.g2) d = t.g2[i] + d;
       if (wd != 0.f) d = d + wd * p;
       float b = d;
       if (!first) {

@@ -21,13 +21,31 @@ class FusedSGD(torch.optim.Optimizer):
         if len(self.param_groups) > 8:
             raise ValueError("FusedSGD: at most 8 parameter groups")
         self._tables = {}            # first(bool) -> (pointer key, device tensor table, device chunk table, n_tensors, n_chunks)
+        self._stash = {}             # parameter -> gradient of an earlier backward pass, summed inside the next step()
+
+    def stash_grads(self):
+        """Sets the current gradients aside (p.grad becomes None): the next backward pass then ASSIGNS its gradients instead
+        of accumulating into the old ones (one `add_` launch per parameter), and step() applies stash + grad in the update
+        kernel -- the same single fp32 addition, in AccumulateGrad's operand order."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    if p in self._stash:
+                        self._stash[p] = self._stash[p] + p.grad
+                    else:
+                        self._stash[p] = p.grad
+                    p.grad = None
+
+    def zero_grad(self, set_to_none=True):
+        self._stash.clear()
+        super().zero_grad(set_to_none=set_to_none)
 
     def _table(self, first, rows, device):
         key = tuple(v for r in rows for v in r)
         ent = self._tables.get(first)
         if ent is None or ent[0] != key:
             chunk = L.load().dasac_ema_chunk_elems()
-            chunks = [(i, j) for i, r in enumerate(rows) for j in range((r[3] + chunk - 1) // chunk)]
+            chunks = [(i, j) for i, r in enumerate(rows) for j in range((r[4] + chunk - 1) // chunk)]
             ent = (key, torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(device),
                    torch.tensor(chunks, dtype=torch.int32).to(device), len(rows), len(chunks))
             self._tables[first] = ent
@@ -47,19 +65,25 @@ class FusedSGD(torch.optim.Optimizer):
             if group["momentum"] != momentum or group.get("nesterov") or group.get("dampening", 0.0) != 0.0 or group.get("maximize"):
                 raise NotImplementedError("FusedSGD: one momentum for all groups, no nesterov / dampening / maximize")
             for p in group["params"]:
+                g2 = self._stash.get(p)
                 if p.grad is None:
-                    continue
-                L.require_gpu(p, p.grad)
+                    if g2 is None:
+                        continue
+                    p.grad, g2 = g2, None            # only the stashed pass produced a gradient for this parameter
+                L.require_gpu(p, p.grad, g2)
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
                     raise TypeError("FusedSGD: dense contiguous fp32 parameters only")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if g2 is not None and not g2.is_contiguous():
+                    g2 = g2.contiguous()
                 st = self.state[p]
                 first = st.get("momentum_buffer") is None
                 if first:
                     st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
                 device = p.device
-                rows[first or momentum == 0.0].append((p.data_ptr(), g.data_ptr(), st["momentum_buffer"].data_ptr(), p.numel(), gi))
-                keep.append(g)                           # a made-contiguous copy must outlive the queued launch
+                rows[first or momentum == 0.0].append((p.data_ptr(), g.data_ptr(), 0 if g2 is None else g2.data_ptr(),
+                                                       st["momentum_buffer"].data_ptr(), p.numel(), gi))
+                keep += [g, g2]                          # a made-contiguous copy must outlive the queued launch
                 touched += [p, st["momentum_buffer"]]
         n = len(self.param_groups)
         lr = (ctypes.c_float * n)(*[float(g["lr"]) for g in self.param_groups])
@@ -72,4 +96,5 @@ class FusedSGD(torch.optim.Optimizer):
                                        ctypes.cast(wd, ctypes.c_void_p), n, float(momentum), int(first), L.stream_ptr()),
                     "dasac_sgd_step")
         ops.bump_versions(touched)       # raw-pointer writes: keep autograd's version counters (engine cache keys) honest
+        self._stash.clear()
         return loss

@@ -68,17 +68,25 @@ def prep_batch(tensor, num_groups, group_size, rank=None, world=None, device=Non
     return mine
 
 
-def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_teacher, lr_target, target_only=False):
+def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_teacher, lr_target, target_only=False,
+                        sum_grads_in_optimizer=True):
     """source fwd -> zero_grad -> source bwd (gradients kept) -> target fwd (teacher EMA first when asked)
     -> (LR_TARGET * self_ce) bwd -> one optimiser step.  Returns (source losses, target losses, net_outs)
     with the losses still on the device (no host sync here).  TRAIN.TARGET_ONLY skips the source pass altogether
-    (train.py:274-276) and clears the gradients before the target backward (train.py:226-227)."""
+    (train.py:274-276) and clears the gradients before the target backward (train.py:226-227).
+
+    The reference lets autograd add the target-pass gradients onto the source-pass ones in `.grad` (320 `add_` launches for
+    ResNet-101).  With `FusedSGD` the source gradients are set aside instead (`stash_grads`) and the update kernel applies
+    source + target -- the same sum, bit for bit; after the step `.grad` holds the target-pass gradient only.  Pass
+    sum_grads_in_optimizer=False (or use another optimiser) for the reference's `.grad` contents."""
     losses_src = {}
     if not target_only:
         images, masks = src_batch
         losses_src, _ = net(images, masks)
         optim.zero_grad()
         losses_src["loss_ce"].mean().backward()
+        if sum_grads_in_optimizer and hasattr(optim, "stash_grads"):
+            optim.stash_grads()
     frames1, frames_gt, frames2, affine, affine_inv = tgt_batch
     losses_tgt, outs = net(frames1, frames_gt, frames2, affine, affine_inv, use_teacher=True,
                            update_teacher=update_teacher, T=group_size)

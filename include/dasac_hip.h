@@ -234,7 +234,8 @@ int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t* argmax, in
 int dasac_ema_chunk_elems(void);
 /* torch.optim.SGD(momentum, no nesterov, dampening 0) over all parameters of up to 8 groups in ONE launch
  * (base_trainer.py:63-66 over basenet.py:73-95):  d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf.
- * tensors: device array of {float* p; const float* g; float* buf; int64 n; int64 group}; chunks as for
+ * tensors: device array of {float* p; const float* g; const float* g2 (NULL or a second gradient, summed as g2 + g before
+ * anything else -- what two backward passes would have accumulated into .grad); float* buf; int64 n; int64 group}; chunks as for
  * dasac_ema_update ((tensor, chunk) pairs of dasac_ema_chunk_elems() elements); group_lr/group_wd: HOST arrays. */
 int dasac_sgd_step(const void* tensors, int n_tensors, const int32_t* chunks, int n_chunks,
                    const float* group_lr, const float* group_wd, int n_groups, float momentum, int first,

@@ -45,6 +45,47 @@ def test_fused_sgd_matches_torch_sgd():
     ob.load_state_dict(sd)                                   # layout-compatible with torch.optim.SGD
 
 
+def test_stashed_gradients_sum_inside_the_update_bit_for_bit():
+    """driver.sac_train_iteration sets the source-pass gradients aside and lets the update kernel add the target-pass
+    ones (instead of 320 `add_` launches): same parameters, bit for bit, as accumulating into .grad first; a parameter
+    that only one of the two passes touched is handled; zero_grad drops the stash."""
+    from dasac_hip.optim import FusedSGD
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 3, 7, 7), (64,), (5000,), (4097,)]
+    pa = [nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    pb = [nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:2], "lr": 2.5e-4, "weight_decay": 5e-4}, {"params": ps[2:], "lr": 5e-3, "weight_decay": 0.0}]
+    oa, ob = FusedSGD(groups(pa), momentum=0.9), FusedSGD(groups(pb), momentum=0.9)
+    for it in range(3):
+        g1 = [torch.randn(a.shape, generator=g).cuda() for a in pa]
+        g2 = [torch.randn(a.shape, generator=g).cuda() for a in pa]
+        oa.zero_grad()                                       # as driver.sac_train_iteration does before the source backward
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i != 3:
+                a.grad = g1[i].clone()
+        oa.stash_grads()
+        assert all(a.grad is None for a in pa)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i != 2:
+                a.grad = g2[i].clone()                       # parameter 2: source pass only; parameter 3: target pass only
+            b.grad = g1[i].clone() if i != 3 else None
+            if i != 2:
+                if b.grad is None:
+                    b.grad = g2[i].clone()
+                else:
+                    b.grad += g2[i]                          # what AccumulateGrad does
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.equal(a, b) and torch.equal(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"])
+    pa[0].grad = torch.ones_like(pa[0])
+    oa.stash_grads()
+    oa.zero_grad()
+    before = pa[0].detach().clone()
+    oa.step()                                                # nothing stashed, no gradient: no update
+    assert torch.equal(pa[0], before)
+
+
 def test_training_with_fused_sgd_equals_torch_sgd():
     """Three SAC-free training steps of the RN101 model: the fused optimiser and torch.optim.SGD give the same loss
     curve, i.e. the packed-weight / BN-fold caches see every raw-pointer update."""
