@@ -425,8 +425,16 @@ class HostClassVectors:
     after the kernel that updates it; `finish()` (called after the warp/pool kernels were queued, so the GPU has
     work while the host waits) runs the two formulas on the host and uploads them without blocking."""
 
+    _pinned = {}          # chi's storage -> (chi buffer, vectors buffer): pinned once per model, reused every step
+
     def __init__(self, running_conf):
-        self.host = torch.empty(running_conf.shape, dtype=torch.float32).pin_memory()
+        key = (running_conf.device.index, running_conf.data_ptr(), tuple(running_conf.shape))
+        bufs = HostClassVectors._pinned.get(key)
+        if bufs is None:
+            bufs = (torch.empty(running_conf.shape, dtype=torch.float32).pin_memory(),
+                    torch.empty((2,) + tuple(running_conf.shape), dtype=torch.float32).pin_memory())
+            HostClassVectors._pinned[key] = bufs
+        self.host, self.vecs = bufs
         self.host.copy_(running_conf.detach(), non_blocking=True)
         self.done = torch.cuda.Event()
         self.done.record()
@@ -434,8 +442,8 @@ class HostClassVectors:
 
     def finish(self, beta, focal_p, want_disc=True):
         self.done.synchronize()
-        chi = self.host
-        vecs = torch.empty((2,) + tuple(chi.shape), dtype=torch.float32).pin_memory()
+        chi, vecs = self.host, self.vecs
+        # (the previous step's upload from `vecs` finished long ago: every step waits on `done` after queueing it)
         vecs[0] = 1 - torch.exp(-chi / beta) if want_disc else 1.0
         vecs[1] = (1 - chi.clamp(0.)) ** focal_p
         dev = vecs.to(self.device, non_blocking=True)
