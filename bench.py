@@ -181,8 +181,13 @@ def main():
         # the same K steps once more in the other arithmetic (outside the contract's timed region; reported as "alt")
         other = "bf16x3" if args.precision == "fp32" else "fp32"
         ops.set_precision(other)
-        dt2, prof2, _ = measure(args.warmup + args.steps, 1)
+        try:
+            dt2, prof2, _ = measure(args.warmup + args.steps, 1)
+        except Exception as exc:      # the extra leg must never cost the contract's line
+            dt2, prof2 = None, None
+            alt = {"dtype": other, "error": repr(exc)[:200]}
         ops.set_precision(args.precision)
+    if not args.no_alt and not baseline and dt2 is not None:
         alt = {"dtype": other, "value": round(world * args.batch * args.steps / dt2, 4), "unit": "images/sec",
                "ms_per_step": round(dt2 / args.steps * 1e3, 3), "kernels": kernel_table(prof2),
                "note": "same step with the forward/data-gradient GEMMs in {} arithmetic; weight gradient and everything else "
@@ -230,7 +235,10 @@ def main():
         if alt is not None:
             line["alt"] = alt
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
-            line["cpu_baseline"] = cpu_baseline(args.size)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.size)
+            except Exception as exc:      # never lose the line to the reported baseline
+                line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "failed: " + repr(exc)[:160]}
         os.write(_JSON_FD, (json.dumps(line) + "\n").encode())
     if world > 1 or force_ddp:
         dist.destroy_process_group()
