@@ -482,7 +482,7 @@ constexpr int kWgPitch = 36;   // row pitch (floats): 16-byte aligned rows, 16 c
 // gives the head as an fp32 bit pattern directly) and stored with 16-bit writes into [octet of 8 pixels][row][8]
 // operand words; the octet pitch rows+2 keeps the 64 lanes of a store on distinct banks and the 16-byte MFMA
 // operand reads of consecutive rows contiguous.
-template <int BM, int BN, int WAVES_M, bool FAST, bool X3>
+template <int BM, int BN, int WAVES_M, bool FAST, bool X3, bool QUAD = false>
 __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
                                                        float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
@@ -536,11 +536,110 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     }
   }
 
+  const bool do_sums = (k_tile == 0) && (Psum != nullptr);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if constexpr (QUAD) {
+    // ---- 1x1 stride-1 convolutions (host: one tap at (0,0), H == OH, W == OW, M % 32 == 0): FOUR consecutive pixels per lane.
+    // Both operands are plain [row][pixel] matrices there, so a lane's four pixels are 16 contiguous bytes: per 64 MFMAs a
+    // thread issues 4+4 dwordx4 loads and 4+4 ds_write_b128 instead of 16+16 dword loads and 16+16 ds_write_b32.  Quads that
+    // leave the split or the image (the dz / x tensors are [N][rows][OH*OW]: a quad may straddle two images) send their
+    // whole wave through a per-element path for that step.
+    static_assert(FAST && !X3 && BM % 32 == 0 && BN % 32 == 0, "quad loader: fp32, one tap per k tile, 32-row passes");
+    constexpr int AQ = BM / 32, BQ = BN / 32;
+    const int pq = t & 7, prow4 = t >> 3;                  // loader: pixel quad of the step, row within a 32-row pass
+    f32x4 qa[AQ], qb[BQ];
+    float qsum[AQ];
+#pragma unroll
+    for (int i = 0; i < AQ; ++i) qsum[i] = 0.f;
+    const int zimg_q = g.M * OHW;
+    int pix = p_begin + 4 * pq;                            // first pixel of this thread's quad (advanced by kWgPix per step)
+    int pn = pix / OHW, prr = pix - pn * OHW;              // image, flat position inside it
+#define DASAC_WGQ_LOAD()                                                                             \
+  {                                                                                                  \
+    const bool whole = (pix + 3 < p_end) & (prr + 3 < OHW);                                          \
+    if (__builtin_amdgcn_ballot_w64(!whole) == 0) {                                                  \
+      const unsigned vz = (unsigned)(pn * zimg_q + prr + prow4 * OHW) * 4u;                          \
+      const unsigned vx = (unsigned)(pn * g.CxHW + prr + prow4 * planeHW) * 4u;                      \
+      _Pragma("unroll") for (int i = 0; i < AQ; ++i) qa[i] = buf_f32x4(rz, vz, (m0 + i * 32) * OHW * 4); \
+      _Pragma("unroll") for (int i = 0; i < BQ; ++i) qb[i] = buf_f32x4(rx, vx, (e0.w + i * 32 * planeHW) * 4); \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+        int re = prr + e, ne = pn;                                                                   \
+        if (re >= OHW) { re -= OHW; ++ne; }                                                          \
+        const bool ve = pix + e < p_end;                                                             \
+        const unsigned vz = ve ? (unsigned)(ne * zimg_q + re + prow4 * OHW) * 4u : kPoison;          \
+        const unsigned vx = ve ? (unsigned)(ne * g.CxHW + re + prow4 * planeHW) * 4u : kPoison;      \
+        _Pragma("unroll") for (int i = 0; i < AQ; ++i) qa[i][e] = buf_f32(rz, vz, (m0 + i * 32) * OHW * 4); \
+        _Pragma("unroll") for (int i = 0; i < BQ; ++i) qb[i][e] = buf_f32(rx, vx, (e0.w + i * 32 * planeHW) * 4); \
+      }                                                                                              \
+    }                                                                                                \
+    if (do_sums) {                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < AQ; ++i) qsum[i] += (qa[i].x + qa[i].y) + (qa[i].z + qa[i].w); \
+    }                                                                                                \
+    pix += kWgPix;                                                                                   \
+    prr += kWgPix;                                                                                   \
+    while (prr >= OHW) { prr -= OHW; ++pn; }                                                         \
+  }
+#define DASAC_WGQ_STORE()                                                                            \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < AQ; ++i)                                                   \
+      *reinterpret_cast<f32x4*>(&sA[0][(prow4 + i * 32) * kWgPitch + 4 * pq]) = qa[i];               \
+    _Pragma("unroll") for (int i = 0; i < BQ; ++i)                                                   \
+      *reinterpret_cast<f32x4*>(&sB[0][(prow4 + i * 32) * kWgPitch + 4 * pq]) = qb[i];               \
+  }
+    if (steps > 0) {
+      DASAC_WGQ_LOAD();
+      DASAC_WGQ_STORE();
+    }
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      if (s + 1 < steps) DASAC_WGQ_LOAD();
+      const float* a_base = &sA[0][(wm * WM + li) * kWgPitch + 4 * lh];
+      const float* b_base = &sB[0][(wn * WN + li) * kWgPitch + 4 * lh];
+#pragma unroll
+      for (int gq = 0; gq < kWgPix / 8; ++gq) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * kWgPitch + 8 * gq);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * kWgPitch + 8 * gq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (s + 1 < steps) {
+        DASAC_WGQ_STORE();
+        __syncthreads();
+      }
+    }
+#undef DASAC_WGQ_LOAD
+#undef DASAC_WGQ_STORE
+    if (do_sums) {
+      // the 8 lanes of a row hold its 32 pixels (4 each): butterfly over the three low lane bits
+#pragma unroll
+      for (int i = 0; i < AQ; ++i) {
+        float v = qsum[i];
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (pq == 0) Psum[(size_t)split * g.Mpad + m0 + prow4 + i * 32] = v;
+      }
+    }
+  } else {
   float ra[A_LOADS], rb[B_LOADS];
   float rsum[A_LOADS];                                   // per-row sums of dZ (only the k_tile 0 blocks)
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) rsum[i] = 0.f;
-  const bool do_sums = (k_tile == 0) && (Psum != nullptr);
   const int zimg = g.M * OHW;                            // dZ image stride
 
   // pixel cursor of this thread (advanced by kWgPix per step)
@@ -607,14 +706,6 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) sA[buf][(prow + i * 8) * kWgPitch + pl] = ra[i]; \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) sB[buf][(prow + i * 8) * kWgPitch + pl] = rb[i]; \
   }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (steps > 0) {
     DASAC_WG_LOAD();
@@ -688,6 +779,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
       if (pl == 0) Psum[(size_t)split * g.Mpad + m0 + prow + i * 8] = v;
     }
   }
+  }   // !QUAD
   // partial slab [split][Mpad][Kpad], k contiguous
   float* slab = P + (size_t)split * g.Mpad * g.Kpad;
 #pragma unroll
@@ -1154,10 +1246,19 @@ static int conv_wgrad_impl(bool x3, const float* dz, const float* x, const int32
     return DASAC_OK;
   }
   switch (bm) {
-    case 128:
-      if (fast) launch_wgrad<128, 128, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
+    case 128: {
+      // 1x1 stride-1 layers: both operands are plain [row][pixel] matrices -> four pixels per lane (conv_wgrad<..., QUAD>)
+      static const int quad_mode = getenv("DASAC_WGRAD_QUAD") ? atoi(getenv("DASAC_WGRAD_QUAD")) : 1;
+      const bool quad = quad_mode && fast && !x3 && K == Cx && stride == 1 && H == OH && W == OW && M % 128 == 0;   // one tap, no padding
+      if (quad) {
+        const int m_tiles = g.Mpad / 128, k_tiles = g.Kpad / 128;
+        const int grid = (m_tiles * k_tiles * splits + kNumXcd - 1) / kNumXcd * kNumXcd;
+        hipLaunchKernelGGL((conv_wgrad<128, 128, 2, true, false, true>), dim3(grid), dim3(kThreads), 0, s, dz, x, tab, P, Psum, g,
+                           m_tiles, k_tiles, splits, per);
+      } else if (fast) launch_wgrad<128, 128, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       else launch_wgrad<128, 128, 2, false>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       break;
+    }
     case 64:
       if (fast) launch_wgrad<64, 128, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       else launch_wgrad<64, 128, 2, false>(x3, dz, x, tab, P, Psum, g, splits, per, s);
