@@ -1,4 +1,4 @@
-"""Register / scratch budget of the three hot GEMM instantiations (VERDICT r1 #6b): cross-compiles conv_igemm.hip to gfx950
+"""Register / scratch budget of the four hot GEMM instantiations (VERDICT r1 #6b): cross-compiles conv_igemm.hip to gfx950
 assembly (no GPU needed, ~10 s) and checks that
   * the tile-per-block forward/dgrad kernel stays at <= 128 VGPRs (4 waves per SIMD) and the persistent stream-K variant and
     the weight-gradient kernel at <= 168 (3 waves per SIMD),
@@ -16,7 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HOT = {
     "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0EEE": 128,      # <128,128,2,16,FAST,tile-per-block,fp32>
     "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0EEE": 168,      # stream-K
-    "conv_wgradILi128ELi128ELi2ELb1ELb0EEE": 168,
+    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb0EEE": 168,
+    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb1EEE": 168,        # QUAD: four pixels per lane (1x1 stride-1 layers)
 }
 
 
