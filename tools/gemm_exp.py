@@ -1,6 +1,7 @@
-"""Scheduling experiments on the hot GEMM shapes of a cfg-3 step (B=8, 97x97): one line per (shape, pass) with TFLOP/s.
-Environment (read once per process by the library): DASAC_GEMM_EXP / DASAC_WGRAD_EXP bit masks.
-Usage (GPU box): DASAC_GEMM_EXP=1 python tools/gemm_exp.py [tag]"""
+"""The hot GEMM shapes of a cfg-3 step in isolation (B=8, 97x97): one line per shape with the TFLOP/s of the forward, the data
+gradient (residual accumulate + ReLU mask) and the weight gradient -- the A/B harness of the experiments in DESIGN.md 5a (the
+library reads its switches once per process: DASAC_STREAMK, DASAC_HYBRID, DASAC_WGRAD_QUAD, ...; 10 iterations per number:
+compare within ONE run, boxes differ by a few per cent).  Usage (GPU box): python tools/gemm_exp.py [tag]"""
 import os
 import sys
 
@@ -35,7 +36,7 @@ def timeit(fn, iters=10):
 
 if __name__ != "__main__":
     SHAPES = []
-tag = sys.argv[1] if len(sys.argv) > 1 else "gemm_exp=%s wgrad_exp=%s" % (os.environ.get("DASAC_GEMM_EXP", "0"), os.environ.get("DASAC_WGRAD_EXP", "0"))
+tag = sys.argv[1] if len(sys.argv) > 1 else "streamk=%s quad=%s" % (os.environ.get("DASAC_STREAMK", "1"), os.environ.get("DASAC_WGRAD_QUAD", "1"))
 out = []
 for name, cin, cout, br, with_res in SHAPES:
     spec = ops.ConvSpec(cin, cout, [br], 1)
