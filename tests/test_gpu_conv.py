@@ -14,6 +14,10 @@ CASES = [
     # name, cin, cout, branches[(kh,kw,dil,pad)], stride, (N,H,W)
     ("1x1", 64, 256, [(1, 1, 1, 0)], 1, (2, 25, 33)),
     ("1x1_s2", 256, 128, [(1, 1, 1, 0)], 2, (2, 25, 33)),
+    # the four-pixels-per-lane weight-gradient loader (conv_wgrad<..., QUAD>: 1x1, stride 1, Cin % 128 == 0, Cout % 128 == 0):
+    # 9x13 = 117 pixels per image (quads straddle images), 351 pixels in all (a ragged last step); then two k tiles x two m tiles
+    ("1x1_quad_ragged", 128, 128, [(1, 1, 1, 0)], 1, (3, 9, 13)),
+    ("1x1_quad", 256, 256, [(1, 1, 1, 0)], 1, (2, 25, 33)),
     ("3x3_d2", 32, 64, [(3, 3, 2, 2)], 1, (2, 19, 23)),
     ("3x3_d4_big", 128, 128, [(3, 3, 4, 4)], 1, (1, 33, 31)),
     ("3x3_d1_c19", 48, 19, [(3, 3, 1, 1)], 1, (3, 9, 13)),
