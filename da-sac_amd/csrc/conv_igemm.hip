@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     } else {                                                                                         \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
         int re = prr + e, ne = pn;                                                                   \
-        if (re >= OHW) { re -= OHW; ++ne; }                                                          \
+        while (re >= OHW) { re -= OHW; ++ne; } /* maps smaller than a quad: several images per quad */ \
         const bool ve = pix + e < p_end;                                                             \
         const unsigned vz = ve ? (unsigned)(ne * zimg_q + re + prow4 * OHW) * 4u : kPoison;          \
         const unsigned vx = ve ? (unsigned)(ne * g.CxHW + re + prow4 * planeHW) * 4u : kPoison;      \

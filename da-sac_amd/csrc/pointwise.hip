@@ -597,3 +597,60 @@ extern "C" int dasac_iou_counts(const float* logits, const int64_t* gt, int B, i
   DASAC_CHECK_LAUNCH("iou_counts");
   return DASAC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Label preparation and Dropout2d masks (what was left on ATen inside the step)
+// ------------------------------------------------------------------------------------------------
+namespace dasac {
+
+// models/sac.py:337-338: ignore_mask = (y == -1); y[ignore_mask] = 255  -- one pass, in place
+__global__ __launch_bounds__(256) void label_pad_mask(int64_t* __restrict__ y, uint8_t* __restrict__ mask, int64_t n,
+                                                      int64_t pad_label, int64_t ignore_label) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const bool pad = y[i] == pad_label;
+    mask[i] = pad ? 1 : 0;
+    if (pad) y[i] = ignore_label;
+  }
+}
+
+// Philox4x32-10 (Salmon et al., SC'11): counter (i, stream offset), key = seed
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * ctr.x, p1 = (uint64_t)0xCD9E8D57u * ctr.z;
+    ctr = make_uint4((uint32_t)(p1 >> 32) ^ ctr.y ^ key.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ ctr.w ^ key.y, (uint32_t)p0);
+    key.x += 0x9E3779B9u;
+    key.y += 0xBB67AE85u;
+  }
+  return ctr;
+}
+
+// Dropout2d (fcn.py:52,56): per (n, c) plane  keep/(1-p) with keep ~ Bernoulli(1-p)
+__global__ __launch_bounds__(256) void dropout_planes(uint64_t seed, uint64_t offset, float p, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)),
+                                make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);      // uniform on [0, 1), 24 bits
+  out[i] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+}  // namespace dasac
+
+extern "C" int dasac_label_pad_mask(int64_t* labels, uint8_t* mask, int64_t n, int pad_label, int ignore_label,
+                                    dasac_stream_t stream) {
+  DASAC_REQUIRE(labels && mask && n > 0, "label_pad_mask: bad arguments");
+  hipLaunchKernelGGL(label_pad_mask, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), labels, mask, n,
+                     (int64_t)pad_label, (int64_t)ignore_label);
+  DASAC_CHECK_LAUNCH("label_pad_mask");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_dropout_planes(uint64_t seed, uint64_t offset, float p, int64_t planes, float* keep_scale,
+                                    dasac_stream_t stream) {
+  DASAC_REQUIRE(keep_scale && planes > 0 && p >= 0.f && p < 1.f, "dropout_planes: bad arguments");
+  hipLaunchKernelGGL(dropout_planes, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, as_stream(stream), seed, offset, p,
+                     planes, keep_scale);
+  DASAC_CHECK_LAUNCH("dropout_planes");
+  return DASAC_OK;
+}

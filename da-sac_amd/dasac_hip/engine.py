@@ -132,6 +132,14 @@ def _ver(t):
     return (t.data_ptr(), t._version)
 
 
+def _copy_into(out, src):
+    """A second parameter that receives the same gradient (the bias of every ASPP branch): its own tensor."""
+    if out is None:
+        return src.clone()
+    out.view(-1).copy_(src.view(-1))
+    return out
+
+
 class Engine:
     """Executes a Plan.  Keeps per-layer caches of gather tables (by spatial size) and of packed
     weights / folded BN vectors (invalidated by the parameters' version counters)."""
@@ -290,7 +298,7 @@ class Engine:
                     # the draw by setting `module.keep_mask` ([B,C], already divided by 1-p) -- parity needs equal masks.
                     keep_mask = getattr(m, "keep_mask", None)
                     if keep_mask is None:
-                        keep_mask = (torch.rand(xin.shape[:2], device=xin.device) >= m.p).to(torch.float32) / (1.0 - m.p)
+                        keep_mask = ops.dropout_planes(xin.shape[0], xin.shape[1], m.p, xin.device)
                     assert tuple(keep_mask.shape) == tuple(xin.shape[:2]) and keep_mask.is_cuda
                     out = ops.scale_planes(xin, keep_mask)
                     if keep:
@@ -307,12 +315,28 @@ class Engine:
         return acts[self.plan.output], saved
 
     # ---------------------------------------------------------------- backward
-    def backward(self, saved, grad_out, need, trace=None):
+    def backward(self, saved, grad_out, need, trace=None, sink=None):
         """grad_out: gradient w.r.t. the plan output.  need[i]: whether parameter i wants a gradient.
         Returns the list of parameter gradients (None where not needed).  `trace` (debug): dict that
-        receives the finished activation gradient of every slot."""
+        receives the finished activation gradient of every slot.
+
+        `sink` (dasac_hip.parallel.GradSink or None): where parameter gradients are WRITTEN and who is told when a layer's
+        are complete -- `sink.alloc(j)` returns the destination of parameter j (a slice of one flat reduction buffer),
+        `sink.done(indices)` is called after each op, in backward order, so that a bucket's all-reduce can start while
+        the layers below it are still being differentiated (DistributedDataParallel's overlap, train.py:104,133,232)."""
         acts, aux = saved["acts"], saved["aux"]
         grads = [None] * len(self.params)
+
+        def dest(j):
+            return sink.alloc(j) if (sink is not None and need[j]) else None
+
+        def sums_dest(b_idx, is_bias_grad, cout, device):
+            """Per-channel sums of dz: they ARE the bias gradient of a conv without (or with batch-statistics) BN -- then they
+            are written straight to that gradient's destination -- and an intermediate of bn_param_grads otherwise."""
+            wanted = [j for j in b_idx if need[j]]
+            out = dest(wanted[0]) if (is_bias_grad and wanted) else None
+            return torch.empty(cout, dtype=torch.float32, device=device) if out is None else out.view(cout)
+
         g = {self.plan.output: grad_out.contiguous()}
         # the d-gamma dot terms of all frozen-BN convs accumulate into slices of ONE zero-filled vector (one fill kernel
         # per backward pass instead of one per layer)
@@ -350,15 +374,16 @@ class Engine:
                     ex, nw_ = op.expanded, len(op.convs)
                     d = ex.scatter(dz)
                     if any(need[j] for j in op.pidx[:nw_]):
-                        dws = ex.wgrad(d, xin, [c.weight.detach() for c in op.convs], self.table_e(op, H, W, False, xin.device))
+                        dws = ex.wgrad(d, xin, [c.weight.detach() for c in op.convs], self.table_e(op, H, W, False, xin.device),
+                                       outs=[dest(j) for j in op.pidx[:nw_]])
                         for j, dw in zip(op.pidx[:nw_], dws):
                             if need[j]:
                                 grads[j] = dw
                     if op.has_bias and any(need[j] for j in op.pidx[nw_:]):
-                        sums = ops.channel_sums(dz)
-                        for n_, j in enumerate(op.pidx[nw_:]):
-                            if need[j]:
-                                grads[j] = sums if n_ == 0 else sums.clone()
+                        wanted = [j for j in op.pidx[nw_:] if need[j]]
+                        sums = ops.channel_sums(dz, out=dest(wanted[0]))
+                        for n_, j in enumerate(wanted):              # every branch bias sees the same gradient
+                            grads[j] = sums if n_ == 0 else _copy_into(dest(j), sums)
                     if op.src != 0:
                         pending[op.src] -= 1
                         last = pending[op.src] == 0
@@ -366,14 +391,18 @@ class Engine:
                         g[op.src] = ex.dgrad(d, self.packed_e(op, True), self.table_e(op, H, W, True, dz.device), (H, W),
                                              res=g.get(op.src), mask=mask)
                     acts.pop(op.dst, None)
+                    if sink is not None:
+                        sink.done([j for j in op.pidx if need[j]])
                     continue
                 dy_out = dz                       # gradient w.r.t. the op output (what a residual input receives)
                 train_bn = i in aux
                 nw = len(op.convs)
                 if train_bn:
                     z, stats = aux.pop(i)
-                    bn_need = any(need[j] for j in op.pidx[nw + (nw if op.has_bias else 0):])
-                    dz, dg, db = ops.bn_train_backward(dz, z, stats, op.bn.weight.detach(), want_params=bn_need)
+                    bn_tail = op.pidx[nw + (nw if op.has_bias else 0):]
+                    bn_need = any(need[j] for j in bn_tail)
+                    dz, dg, db = ops.bn_train_backward(dz, z, stats, op.bn.weight.detach(), want_params=bn_need,
+                                                       outs=(dest(bn_tail[0]), dest(bn_tail[1])) if bn_need else (None, None))
                     del z
                     scale, shift, invstd = None, None, None
                 else:
@@ -394,30 +423,33 @@ class Engine:
                         dot = dot_pool[dot_used:dot_used + spec.cout]
                         dot_used += spec.cout
                     if want_bn or want_bias:      # channel sums ride along with the wgrad kernel
-                        sums = torch.empty(spec.cout, dtype=torch.float32, device=dz.device)
+                        sums = sums_dest(b_idx, want_bias and (train_bn or op.bn is None), spec.cout, dz.device)
                     dws = ops.conv_wgrad(spec, dz, xin, [c.weight.detach() for c in op.convs], scale=scale, dot=dot,
-                                         table=self.table(op, H, W, False, xin.device, wgrad=True), sum_dz=sums)
+                                         table=self.table(op, H, W, False, xin.device, wgrad=True), sum_dz=sums,
+                                         outs=[dest(j) for j in op.pidx[:nw]])
                     for j, dw in zip(op.pidx[:nw], dws):
                         if need[j]:
                             grads[j] = dw
                 elif want_bias:
-                    sums = ops.channel_sums(dz)
+                    sums = ops.channel_sums(dz, out=sums_dest(b_idx, train_bn or op.bn is None, spec.cout, dz.device))
                 if train_bn:
                     if want_bias:
                         grads[b_idx[0]] = sums
                 elif op.bn is not None:
                     cb = op.convs[0].bias.detach() if op.has_bias else None
                     dg, db, dcb = ops.bn_param_grads(dot, sums, op.bn.running_mean, invstd, scale, cb,
-                                                     want_gamma=want_bn, want_beta=want_bn, want_bias=want_bias) \
+                                                     want_gamma=want_bn, want_beta=want_bn, want_bias=want_bias,
+                                                     outs=(dest(bn_idx[0]) if want_bn else None, dest(bn_idx[1]) if want_bn else None,
+                                                           dest(b_idx[0]) if want_bias else None)) \
                         if (want_bn or want_bias) else (None, None, None)
                     if want_bn:
                         grads[bn_idx[0]], grads[bn_idx[1]] = dg, db
                     if want_bias:
                         grads[b_idx[0]] = dcb
                 elif want_bias:
-                    for n_, j in enumerate(b_idx):        # every branch bias sees the same gradient
-                        if need[j]:
-                            grads[j] = sums if n_ == 0 else sums.clone()
+                    wanted = [j for j in b_idx if need[j]]
+                    for n_, j in enumerate(wanted):       # every branch bias sees the same gradient
+                        grads[j] = sums if n_ == 0 else _copy_into(dest(j), sums)
                 if op.src != 0:
                     pending[op.src] -= 1
                     last = pending[op.src] == 0
@@ -428,6 +460,8 @@ class Engine:
                                                packed=self.packed(op, True, scale))
                 if op.res is not None:
                     join_identity(op.res, dy_out)
+                if sink is not None:
+                    sink.done([j for j in op.pidx if need[j]])
             elif op.kind == "pool":
                 assert self.consumers[op.src] == 1
                 pending[op.src] -= 1
@@ -446,10 +480,10 @@ class Engine:
 
 class _PlanFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, engine, x, *params):
+    def forward(ctx, engine, sink, x, *params):
         keep = any(p.requires_grad for p in params)
         out, saved = engine.forward(x, keep)
-        ctx.engine = engine
+        ctx.engine, ctx.sink = engine, sink
         ctx.saved = saved if keep else None
         return out
 
@@ -458,16 +492,21 @@ class _PlanFunction(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("dasac_hip engine: the activations of this forward were already consumed by a backward pass "
                                "(retain_graph / a second backward through the same forward is not supported)")
-        need = list(ctx.needs_input_grad[2:])
-        grads = ctx.engine.backward(ctx.saved, grad_out, need)
+        need = list(ctx.needs_input_grad[3:])
+        sink = ctx.sink
+        if sink is not None:
+            grad_out = sink.begin(ctx.engine, need, grad_out)
+        grads = ctx.engine.backward(ctx.saved, grad_out, need, sink=sink)
+        if sink is not None:
+            sink.finish()         # the launch stream waits for the outstanding bucket reductions: .grad is final for any consumer
         ctx.saved = None
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
-def run_plan(engine, x):
-    """logits = plan(x); differentiable w.r.t. every parameter of the plan."""
+def run_plan(engine, x, sink=None):
+    """logits = plan(x); differentiable w.r.t. every parameter of the plan.  `sink`: see Engine.backward."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in engine.params):
-        return _PlanFunction.apply(engine, x, *engine.params)
+        return _PlanFunction.apply(engine, sink, x, *engine.params)
     out, _ = engine.forward(x, keep=False)
     return out
 
@@ -491,7 +530,7 @@ def upsample_bilinear(logits, size):
     """F.interpolate(logits, size, mode='bilinear', align_corners=True) (deeplabv2.py:217).  The result remembers the
     low-resolution tensor it came from, so that a loss on it can send its gradient straight there (`_CELossLow`)."""
     up = _Upsample.apply(logits, tuple(int(s) for s in size))
-    up._dasac_low = logits
+    up._dasac_low = (logits, up._version)      # valid only while `up` still holds U(logits): see _ce
     return up
 
 
@@ -528,8 +567,14 @@ class _CELossLow(torch.autograd.Function):
 
 
 def _ce(logits_up, labels, class_weight, conf):
-    low = getattr(logits_up, "_dasac_low", None)
-    if low is not None and low.requires_grad and torch.is_grad_enabled() and tuple(low.shape[:2]) == tuple(logits_up.shape[:2]):
+    low, version = getattr(logits_up, "_dasac_low", None) or (None, None)
+    # The shortcut sends the loss gradient straight to the low-resolution logits, past `logits_up`'s own autograd edge.
+    # It is taken only while that is indistinguishable from the long way round: `logits_up` was not edited in place since
+    # it was upsampled (version counter) and nobody observes its gradient (retain_grad / tensor hooks).  Otherwise the
+    # loss is differentiated w.r.t. logits_up itself and autograd continues through the upsampling's own backward.
+    watched = logits_up.retains_grad or bool(getattr(logits_up, "_backward_hooks", None))
+    if low is not None and version == logits_up._version and not watched and low.requires_grad and torch.is_grad_enabled() \
+            and tuple(low.shape[:2]) == tuple(logits_up.shape[:2]):
         return _CELossLow.apply(low, logits_up.detach(), labels, class_weight, conf)
     return _CELoss.apply(logits_up, labels, class_weight, conf)
 

@@ -236,9 +236,10 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
     return relu_mask(dx, mask) if mask is not None else dx
 
 
-def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=None):
+def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=None, outs=None):
     """Returns [dW per branch]; optionally accumulates dot[co] += sum_k W*G (unscaled G) and fills
-    sum_dz[co] = sum over batch and pixels of dz."""
+    sum_dz[co] = sum over batch and pixels of dz.  `outs`: destination per branch (None entries are allocated) --
+    a gradient sink hands out slices of its flat reduction buffer here."""
     lib = L.load()
     L.require_gpu(dz, x, *weights)
     Nb, Cx, H, W = x.shape
@@ -252,8 +253,8 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=No
         L.check(fn(_c(dz).data_ptr(), x.data_ptr(), table.data_ptr(), Nb, Cx, H, W, OH, OW, spec.stride, M,
                    spec.K, ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
     grads, tap0 = [], 0
-    for w, (kh, kw, _, _) in zip(weights, spec.branches):
-        dw = torch.empty_like(w)
+    for bi, (w, (kh, kw, _, _)) in enumerate(zip(weights, spec.branches)):
+        dw = _dest(None if outs is None else outs[bi], w)
         L.check(lib.dasac_conv_wgrad_finish(ws.data_ptr(), Nb, OH, OW, M, spec.K, _c(w).data_ptr(), L.ptr(scale),
                                             dw.data_ptr(), L.ptr(dot), L.ptr(sum_dz if tap0 == 0 else None), spec.cin, kh * kw,
                                             tap0, L.stream_ptr()),
@@ -268,6 +269,14 @@ def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=No
 # ----------------------------------------------------------------------------------------------
 def _f32(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _dest(out, like):
+    """`out` if given (checked: fp32, contiguous, same element count as `like`), else a fresh tensor shaped like `like`."""
+    if out is None:
+        return torch.empty_like(like, memory_format=torch.contiguous_format)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == like.numel() and out.device == like.device
+    return out
 
 
 def upsample_softmax(logits, size, ignore=None, want_up=True, want_probs=False, want_sums=False):
@@ -470,23 +479,24 @@ def bn_fold(gamma, beta, mean, var, eps, conv_bias=None, want_invstd=True):
     return scale, shift, invstd
 
 
-def bn_param_grads(dot, sum_dz, mean, invstd, scale, conv_bias, want_gamma=True, want_beta=True, want_bias=False):
+def bn_param_grads(dot, sum_dz, mean, invstd, scale, conv_bias, want_gamma=True, want_beta=True, want_bias=False, outs=(None, None, None)):
     lib = L.load()
     Cn = sum_dz.numel()
-    dg = _f32((Cn,), sum_dz) if want_gamma else None
-    db = _f32((Cn,), sum_dz) if want_beta else None
-    dcb = _f32((Cn,), sum_dz) if want_bias else None
+    dg = _dest(outs[0], sum_dz) if want_gamma else None
+    db = _dest(outs[1], sum_dz) if want_beta else None
+    dcb = _dest(outs[2], sum_dz) if want_bias else None
     L.check(lib.dasac_bn_param_grads(L.ptr(dot), sum_dz.data_ptr(), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(conv_bias),
                                      Cn, L.ptr(dg), L.ptr(db), L.ptr(dcb), L.stream_ptr()), "dasac_bn_param_grads")
     return dg, db, dcb
 
 
-def channel_sums(x):
+def channel_sums(x, out=None):
     lib = L.load()
     L.require_gpu(x)
     x = _c(x)
     N, Cn = x.shape[0], x.shape[1]
-    out = _f32((Cn,), x)
+    out = _f32((Cn,), x) if out is None else out
+    assert out.numel() == Cn and out.dtype == torch.float32 and out.is_contiguous()
     L.check(lib.dasac_channel_sums(x.data_ptr(), N, Cn, x[0, 0].numel(), out.data_ptr(), L.stream_ptr()), "dasac_channel_sums")
     return out
 
@@ -551,6 +561,48 @@ def scale_planes(x, plane_scale):
     L.check(lib.dasac_scale_planes(x.data_ptr(), _c(plane_scale).data_ptr(), x.shape[0] * x.shape[1], x[0, 0].numel(),
                                    out.data_ptr(), L.stream_ptr()), "dasac_scale_planes")
     return out
+
+
+def label_pad_mask(labels, pad_label=-1, ignore_label=255):
+    """sac.py:337-338: returns ignore_mask = (labels == -1) (bool, same shape) and rewrites those labels to 255 IN PLACE."""
+    lib = L.load()
+    L.require_gpu(labels)
+    assert labels.dtype == torch.int64
+    work = labels if labels.is_contiguous() else labels.contiguous()
+    mask = torch.empty(labels.shape, dtype=torch.bool, device=labels.device)
+    L.check(lib.dasac_label_pad_mask(work.data_ptr(), mask.data_ptr(), work.numel(), int(pad_label), int(ignore_label),
+                                     L.stream_ptr()), "dasac_label_pad_mask")
+    if work is not labels:
+        labels.copy_(work)                 # a strided caller tensor still sees the in-place rewrite
+    else:
+        torch.autograd.graph.increment_version(labels)
+    return mask
+
+
+_dropout_calls = 0
+
+
+def dropout_planes(B, Cn, p, device):
+    """Dropout2d noise [B, C]: keep/(1-p), drawn on the device (Philox keyed by torch's CUDA seed, one offset per call)."""
+    global _dropout_calls
+    lib = L.load()
+    out = torch.empty((B, Cn), dtype=torch.float32, device=device)
+    seed = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()].initial_seed()
+    _dropout_calls += 1
+    L.check(lib.dasac_dropout_planes(seed & 0xFFFFFFFFFFFFFFFF, _dropout_calls, float(p), B * Cn, out.data_ptr(), L.stream_ptr()),
+            "dasac_dropout_planes")
+    return out
+
+
+def class_sums(probs):
+    """float64 [C] sums over batch and pixels of probs [B,C,H,W] (sac.py:108 before the division)."""
+    lib = L.load()
+    L.require_gpu(probs)
+    probs = _c(probs)
+    B, Cn = probs.shape[0], probs.shape[1]
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=probs.device)
+    L.check(lib.dasac_bn_stats(probs.data_ptr(), B, Cn, probs[0, 0].numel(), sums.data_ptr(), L.stream_ptr()), "dasac_bn_stats")
+    return sums[:Cn]
 
 
 def bump_versions(tensors):
@@ -638,7 +690,7 @@ def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
     return y, (mean, invstd, count, count_dev)
 
 
-def bn_train_backward(dy, z, stats, gamma, want_params=True):
+def bn_train_backward(dy, z, stats, gamma, want_params=True, outs=(None, None)):
     """dy: gradient w.r.t. the BN output (ReLU mask already applied).  Returns (dz, dgamma, dbeta)."""
     lib = L.load()
     L.require_gpu(dy, z)
@@ -655,8 +707,8 @@ def bn_train_backward(dy, z, stats, gamma, want_params=True):
         sums = sums.clone()
         dist.all_reduce(sums)
     dz = torch.empty_like(z)
-    dg = _f32((Cn,), z) if want_params else None
-    db = _f32((Cn,), z) if want_params else None
+    dg = _dest(outs[0], gamma) if want_params else None
+    db = _dest(outs[1], gamma) if want_params else None
     fused = want_params and sums is local                     # one rank: the kernel writes d gamma / d beta itself
     L.check(lib.dasac_bn_bwd_apply(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                    sums.data_ptr(), float(count), L.ptr(count_dev), N, Cn, HW, dz.data_ptr(),
@@ -720,7 +772,7 @@ class ExpandedConv:
                                       L.stream_ptr()), "dasac_tap_scatter")
         return d
 
-    def wgrad(self, d, x, weights, table):
+    def wgrad(self, d, x, weights, table, outs=None):
         """Weight gradients of every branch from the expanded gradient d [B,E,H,W]."""
         lib = L.load()
         B, Cx, H, W = x.shape
@@ -731,8 +783,8 @@ class ExpandedConv:
             L.check(fn(d.data_ptr(), x.data_ptr(), table.data_ptr(), B, Cx, H, W, H, W, 1, self.E, self.spec.cin,
                        ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_conv_wgrad")
         grads, tap0 = [], 0
-        for w, (kh, kw, _, _) in zip(weights, self.spec.branches):
-            dw = torch.empty_like(w)
+        for bi, (w, (kh, kw, _, _)) in enumerate(zip(weights, self.spec.branches)):
+            dw = _dest(None if outs is None else outs[bi], w)
             L.check(lib.dasac_conv_wgrad_finish_expanded(ws.data_ptr(), B, H, W, self.E, self.spec.cin, dw.data_ptr(),
                                                          self.spec.cout, kh * kw, tap0, self.cp, L.stream_ptr()),
                     "dasac_conv_wgrad_finish_expanded")

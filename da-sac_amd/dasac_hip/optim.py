@@ -36,6 +36,18 @@ class FusedSGD(torch.optim.Optimizer):
                         self._stash[p] = p.grad
                     p.grad = None
 
+    def full_grads(self):
+        """{parameter: stash + .grad} -- the gradient the next step() will apply, as the reference's `.grad` would hold it
+        after both backward passes (for clipping / norm logging between the last backward and step())."""
+        out = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                g, g2 = p.grad, self._stash.get(p)
+                if g is None and g2 is None:
+                    continue
+                out[p] = g if g2 is None else (g2 if g is None else g2 + g)
+        return out
+
     def zero_grad(self, set_to_none=True):
         self._stash.clear()
         super().zero_grad(set_to_none=set_to_none)

@@ -77,8 +77,11 @@ def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_tea
 
     The reference lets autograd add the target-pass gradients onto the source-pass ones in `.grad` (320 `add_` launches for
     ResNet-101).  With `FusedSGD` the source gradients are set aside instead (`stash_grads`) and the update kernel applies
-    source + target -- the same sum, bit for bit; after the step `.grad` holds the target-pass gradient only.  Pass
-    sum_grads_in_optimizer=False (or use another optimiser) for the reference's `.grad` contents."""
+    source + target -- on one rank the same sum, bit for bit.  Between the target backward and step(), and after it,
+    `.grad` holds the target-pass gradient only: anything that reads gradients before the step (clipping, norm logging)
+    must use `optim.full_grads()` or pass sum_grads_in_optimizer=False (or another optimiser) for the reference's `.grad`
+    contents.  Under data parallelism the update is mean_r(src_r) + mean_r(tgt_r) where the reference's DDP reduces
+    mean_r(mean(src) + tgt_r): equal in exact arithmetic, one rounding apart in fp32 (not bit-identical)."""
     losses_src = {}
     if not target_only:
         images, masks = src_batch

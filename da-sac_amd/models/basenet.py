@@ -24,6 +24,7 @@ class BaseNet(nn.Module):
         self.not_training = []          # layers whose parameters are frozen by train()
         self.bn_freeze = []             # BN layers that always stay in eval mode
         self._engine = None
+        self._grad_sink = None          # dasac_hip.parallel.GradSink when wrapped by OverlappedDataParallel
 
     # -- LR multipliers [pre-trained, from-scratch] (basenet.py:32-40); subclasses override
     def lr_mult(self):
@@ -108,7 +109,7 @@ class BaseNet(nn.Module):
     def _logits(self, im):
         if self._engine is None or self._engine.stale():      # parameter objects replaced -> re-capture the plan
             self._engine = E.Engine(self._plan())
-        return E.run_plan(self._engine, im)
+        return E.run_plan(self._engine, im, sink=self._grad_sink)
 
     def _segment(self, im, y, with_logits=True):
         """Shared tail of every backbone forward (deeplabv2.py:213-227, fcn.py:136-149)."""

@@ -72,6 +72,24 @@ class SAC(SAC_Baseline):
                         names.append(".".join(x for x in (prefix, mname, bname) if x))
         self._ddp_params_and_buffers_to_ignore = names
 
+    @torch.no_grad()
+    def broadcast_frozen_buffers(self, src=0, group=None):
+        """The buffers exempted above are left out of DistributedDataParallel's construction-time synchronisation as well.
+        Ranks that built or loaded different frozen-BN statistics (from-scratch init, a resume where only rank 0 reads the
+        snapshot) would stay divergent without any error -- call this once after load / resume, before wrapping in DDP
+        (`dasac_hip.parallel.OverlappedDataParallel` does it itself).  No-op without a process group."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        names = set(self._ddp_params_and_buffers_to_ignore)
+        bufs = [b for n, b in self.named_buffers() if n in names and b.is_floating_point()]
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.broadcast(flat, src, group=group)
+        if dist.get_rank(group) != src:
+            o = 0
+            for b in bufs:
+                b.copy_(flat[o:o + b.numel()].view(b.shape))
+                o += b.numel()
+
     def _get_op(self, name):
         op_name = "_{}".format(name)
         assert hasattr(self, op_name), "Pooling OP {} not found".format(op_name)
@@ -103,7 +121,7 @@ class SAC(SAC_Baseline):
     @torch.no_grad()
     def _update_running_conf(self, probs, tolerance=1e-8):
         B, C, H, W = probs.size()
-        sums = probs.sum((0, 2, 3), dtype=torch.float64)
+        sums = ops.class_sums(probs)
         ops.class_state(self.running_conf, sums, B, H * W, self.cfg.THRESHOLD_BETA, self.cfg.STAT_MOMENTUM, True,
                         self.cfg.FOCAL_P, want_disc=False, want_focal=False)
 
@@ -218,8 +236,7 @@ class SAC(SAC_Baseline):
             return self.slow_net(x) if teacher else self.backbone(x)
         if reset_teacher:
             self.slow_init[0] = False
-        ignore_mask = (y == -1)
-        y[ignore_mask] = 255                           # in place, like the reference (sac.py:338)
+        ignore_mask = ops.label_pad_mask(y, -1, 255)    # (y == -1), and y <- 255 there in place like the reference (sac.py:337-338)
         losses, net_outs = self.backbone(x, y)
         if update_teacher:
             print("Updating the teacher")

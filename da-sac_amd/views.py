@@ -164,8 +164,9 @@ class TargetViews:
         self.L, self.zoom, self.guided_hflip = int(group_size), tuple(zoom_range), bool(guided_hflip)
         self.rng = random.Random(seed)
         self.torch_gen = torch.Generator()
-        if seed is not None:
-            self.torch_gen.manual_seed(seed)
+        # seed=None: both generators start from OS entropy (the reference draws ColorJitter from the global torch RNG, which
+        # DataLoader seeds per worker) -- a bare torch.Generator() would start every rank and every run on torch's fixed default
+        self.torch_gen.manual_seed(seed if seed is not None else self.rng.getrandbits(63))
         self.mean = np.asarray(mean, dtype=np.float32)
         self.std = np.asarray(std, dtype=np.float32)
         self.blur, self.jitter, self.jitter_p, self.grey_p = blur, float(jitter), float(jitter_p), float(grey_p)

@@ -274,6 +274,16 @@ int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const
                        const float* gamma, const double* sums, double count, const double* count_dev, int N, int C,
                        int64_t HW, float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);
 
+/* models/sac.py:337-338  `ignore_mask = (y == -1); y[ignore_mask] = 255` in one pass: mask[i] = labels[i] == pad_label,
+ * labels[i] = ignore_label there (in place, like the reference).  labels i64 [n], mask u8 [n]. */
+int dasac_label_pad_mask(int64_t* labels, uint8_t* mask, int64_t n, int pad_label, int ignore_label,
+                         dasac_stream_t stream);
+/* nn.Dropout2d(p) in train mode (models/fcn.py:52,56): keep_scale[plane] = Bernoulli(1-p) / (1-p) for the (n, c) planes,
+ * consumed by dasac_scale_planes.  Counter-based Philox4x32-10: the draw is a pure function of (seed, offset, plane) --
+ * the caller advances `offset` per call; it is NOT ATen's stream (parity tests inject the mask instead). */
+int dasac_dropout_planes(uint64_t seed, uint64_t offset, float p, int64_t planes, float* keep_scale,
+                         dasac_stream_t stream);
+
 /* Validation counts (utils/metrics.py:9-53, train.py:339-469): counts[0:C] += tp, counts[C:2C] += fp,
  * counts[2C:3C] += fn of argmax_c logits vs gt (pixels with gt == ignore_index skipped); the caller
  * zeroes `counts` (int64 [3*C]) once per evaluation and all-reduces it across ranks. */

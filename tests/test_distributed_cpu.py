@@ -146,3 +146,36 @@ def test_prep_batch_single_process_and_bad_world():
     assert torch.equal(driver.prep_batch(t, 2, 4, rank=0, world=1), t.flatten(0, 1))     # train.py:186-187
     with pytest.raises(AssertionError, match="Batch size does not fit world size"):
         driver.prep_batch(t, 2, 4, rank=0, world=3)
+
+
+def test_gradient_sink_layout_covers_every_trainable_parameter_in_backward_order():
+    """dasac_hip.parallel.GradSink: slices of the flat reduction buffer are disjoint, 256-byte aligned, ordered as the
+    backward pass completes them (ASPP first, stem last) and cut into contiguous buckets (host logic only)."""
+    from types import SimpleNamespace as NS
+    import torch.nn as nn
+    import models
+    from dasac_hip import engine as E
+    from dasac_hip.parallel import GradSink, _trainable_backbones
+    from oracle.step_ref import DEFAULT_CFG
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False))
+    net = models.get_model(cfg, 0, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    net.train()
+    assert _trainable_backbones(net) == [net.backbone]           # the teacher has no gradients, SAC itself no plan
+    eng = E.Engine(net.backbone._plan())
+    need = [p.requires_grad for p in eng.params]
+    sink = GradSink(bucket_bytes=32 << 20)
+    sink._build_layout(eng, need)
+    spans = sorted((sink._offsets[j], eng.params[j].numel(), j) for j in sink._offsets)
+    assert len(spans) == sum(need) == 320
+    for (o, n, _), (o2, _, _) in zip(spans, spans[1:]):
+        assert o % 64 == 0 and o + n <= o2
+    assert spans[-1][0] + spans[-1][1] <= sink._total
+    names = {id(p): n for n, p in net.backbone.named_parameters()}
+    assert names[id(eng.params[spans[0][2]])].startswith("model.layer5.")      # first slice: the classifier
+    assert names[id(eng.params[spans[-1][2]])].startswith(("model.conv1", "model.bn1"))
+    # buckets tile [0, total) without gaps; the first one is small so that the first reduction starts early
+    assert sink._buckets[0][0] == 0 and sink._buckets[-1][1] == sink._total
+    for (_, hi, _), (lo, _, _) in zip(sink._buckets, sink._buckets[1:]):
+        assert hi == lo
+    sizes = [(hi - lo) * 4 for lo, hi, _ in sink._buckets]
+    assert sizes[0] < 32 << 20 and max(sizes) < 48 << 20 and len(sizes) >= 5

@@ -1,0 +1,50 @@
+"""Full-resolution end-to-end parity (cfg-3's 769x769 crops): the sample bench.py times the CPU oracle on -- 1 source + 1
+target crop, student forward/backward each, teacher forward, SAC head, SGD step -- runs through the HIP module too and the
+two are compared (losses, label map, class prior, sampled gradients and updated parameters); and `bench.py --gpus 2`
+launches its own ranks (two on the one GPU of the box) and prints the contract's JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cfg3_resolution_sample_matches_the_oracle():
+    sys.path.insert(0, ROOT)
+    import bench
+    (_, cores), cmp_ = bench.parity_fullres(769)
+    print("parity_fullres:", cmp_, "cores", cores)
+    assert cmp_["labelled_frac"] > 0.05                       # the thresholds fire: the label comparison is not vacuous
+    assert cmp_["loss_ce_rel"] <= 1e-4
+    assert cmp_["self_ce_rel"] <= 5e-3
+    assert cmp_["label_mismatch_frac"] < 1e-3                 # fp32 probabilities differ at 1e-6: borderline pixels only
+    assert cmp_["running_conf_max_abs"] <= 1e-6
+    # north_star: logits / grads within 1e-3 rel (of the tensor max); free-running gradients carry the borderline-ReLU effect
+    # that the fp64 arbitration of test_gpu_models.py explains -- at 591k pixels per plane one flipped unit weighs far less
+    assert cmp_["grad_max_err_over_tensor_max"] <= 1e-3
+    assert cmp_["param_max_err_over_tensor_max"] <= 1e-5
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run (what the driver runs for the scaling curve): two ranks, here
+    both on the single device of the box (DASAC_BENCH_RANKS_PER_GPU=2 -> gloo transport), tiny crops; exactly one JSON line
+    on stdout with n_gpus = 2 and the process group's world size."""
+    env = dict(os.environ, DASAC_BENCH_RANKS_PER_GPU="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "129",
+           "--batch", "2", "--groups", "1", "--views", "2", "--profile-steps", "1"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 2
+    d = line["config"]["distributed"]
+    assert d["world_size"] == 2 and d["self_launched"] and d["wrapper"] == "overlapped" and d["ranks_per_gpu"] == 2
+    assert line["config"]["global_batch"] == 4
+    assert "roofline" in line and line["kernels"]

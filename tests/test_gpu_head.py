@@ -252,3 +252,67 @@ def test_upsample_softmax_four_pixels_per_thread_edges(shape):
     assert rel_err(up, ref_up) < TOL
     assert rel_err(sums, ref_p.sum((0, 2, 3))) < 1e-5
     assert rel_err(probs, ref_p * (~ign)[:, None]) < TOL
+
+
+def test_label_pad_mask_class_sums_and_dropout_planes():
+    """The three small kernels that took the last ATen arithmetic off the step: sac.py:337-338 label preparation,
+    sac.py:108 class sums (float64) and Dropout2d's per-plane noise (fcn.py:52,56)."""
+    import torch
+    from dasac_hip import ops
+    g = torch.Generator().manual_seed(4)
+    y = torch.randint(-1, 19, (3, 37, 41), generator=g)
+    y[0, :5] = -1
+    y[1, 3:9, 7:20] = 255
+    want_mask, want_y = (y == -1), y.clone()
+    want_y[want_mask] = 255
+    yd = y.cuda()
+    mask = ops.label_pad_mask(yd)
+    assert mask.dtype == torch.bool and torch.equal(mask.cpu(), want_mask) and torch.equal(yd.cpu(), want_y)
+    ys = y.cuda().transpose(1, 2)                                # strided view: still rewritten in place
+    mask = ops.label_pad_mask(ys)
+    assert torch.equal(mask.cpu(), want_mask.transpose(1, 2)) and torch.equal(ys.cpu(), want_y.transpose(1, 2))
+
+    probs = torch.rand(2, 19, 33, 49, generator=g)
+    sums = ops.class_sums(probs.cuda())
+    assert sums.dtype == torch.float64 and sums.shape == (19,)
+    assert torch.allclose(sums.cpu(), probs.double().sum((0, 2, 3)), rtol=1e-12, atol=0)
+
+    torch.cuda.manual_seed(11)
+    a = ops.dropout_planes(64, 4096, 0.1, torch.device("cuda", 0))
+    b = ops.dropout_planes(64, 4096, 0.1, torch.device("cuda", 0))
+    vals = set(a.unique().tolist())
+    assert vals == {0.0, float(torch.tensor(1.0 / 0.9, dtype=torch.float32))}
+    assert abs(float((a == 0).float().mean()) - 0.1) < 5e-3 and not torch.equal(a, b)       # Bernoulli(0.9), a new draw per call
+    rows = (a == 0).float().mean(1)
+    assert float(rows.std()) < 0.02                                                          # no structure across planes
+
+
+def test_loss_shortcut_to_low_resolution_is_dropped_when_logits_up_is_edited_or_watched():
+    """engine._ce differentiates a loss on an upsampled tensor w.r.t. the low-resolution logits directly; that is only valid
+    while logits_up still IS the upsampling and nobody observes its gradient."""
+    import torch
+    from dasac_hip import engine as E
+    g = torch.Generator().manual_seed(2)
+    low0 = torch.randn(2, 19, 9, 13, generator=g).cuda()
+    y = torch.randint(0, 19, (2, 65, 97), generator=g).cuda()
+
+    def grads(edit, watch):
+        low = low0.clone().requires_grad_(True)
+        up = E.upsample_bilinear(low, (65, 97))
+        if edit:
+            up.mul_(2.0)
+        if watch:
+            up.retain_grad()
+        E.ce_mean_all_pixels(up, y).backward()
+        return low.grad.clone(), up.grad
+
+    g_plain, none = grads(False, False)
+    assert none is None
+    g_watch, up_grad = grads(False, True)
+    assert up_grad is not None and float(up_grad.abs().sum()) > 0          # the observer sees the loss gradient
+    assert torch.allclose(g_watch, g_plain, rtol=1e-5, atol=1e-9)
+    g_edit, _ = grads(True, False)                                          # loss of 2*U(low): NOT the gradient of loss(U(low))
+    want = torch.autograd.grad(torch.nn.functional.cross_entropy(2 * torch.nn.functional.interpolate(
+        (lr := low0.clone().cpu().requires_grad_(True)), (65, 97), mode="bilinear", align_corners=True), y.cpu()), lr)[0]
+    assert torch.allclose(g_edit.cpu(), want, rtol=1e-3, atol=1e-8)
+    assert not torch.allclose(g_edit, g_plain, rtol=1e-2)

@@ -1,0 +1,168 @@
+"""dasac_hip.parallel.OverlappedDataParallel: the gradient all-reduce issued bucket by bucket from INSIDE the engine's
+backward pass (DistributedDataParallel's overlap, /root/reference/train.py:104,133,232).  Checked against (1) the bare
+module -- the flat-buffer gradient sink must not change a bit -- and (2) two ranks on the one GPU of the box (gloo
+transport) against a one-process emulation that averages the per-rank gradients by hand."""
+import os
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from oracle import nets_ref as N
+from oracle.step_ref import DEFAULT_CFG
+
+pytestmark = pytest.mark.gpu
+CRIT = nn.CrossEntropyLoss(ignore_index=255, reduction="none")
+_PROBE = ("model.conv1.weight", "model.layer2.1.bn2.weight", "model.layer3.5.conv2.weight", "model.layer5.conv2d_list.1.bias",
+          "model.layer5.conv2d_list.3.weight", "model.layer4.0.downsample.1.bias")
+
+
+def _build(seed=3):
+    import models
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False))
+    net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT)
+    net.backbone.load_state_dict(N.resnet101_state(seed=seed, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
+    net.cuda().train()
+    return cfg, net
+
+
+def _two_passes(step_net, src, tgt, lr_target):
+    ls, _ = step_net(*src)
+    for p in step_net.parameters():
+        p.grad = None
+    ls["loss_ce"].mean().backward()
+    lt, _ = step_net(tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4], use_teacher=True, update_teacher=True, T=2)
+    (lr_target * lt["self_ce"].mean()).backward()
+    return float(ls["loss_ce"]), float(lt["self_ce"])
+
+
+def test_gradient_sink_is_bit_identical_to_the_plain_module_and_grads_share_one_buffer():
+    import driver
+    from dasac_hip.parallel import OverlappedDataParallel
+    src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=5)
+    cfg, net = _build()
+    plain = _two_passes(net, src, tgt, cfg.LR_TARGET)
+    ref = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    cfg, net2 = _build()
+    wrapped = OverlappedDataParallel(net2, device_ids=[0], bucket_mb=8)
+    got = _two_passes(wrapped, src, tgt, cfg.LR_TARGET)
+    assert plain == got
+    n_checked = 0
+    for n, p in net2.named_parameters():
+        if n in ref:
+            assert torch.equal(p.grad, ref[n]), n
+            n_checked += 1
+    assert n_checked == len(ref) == 320
+    # state dict carries DDP's "module." prefix; several buckets exist; nothing is reduced on one rank
+    assert all(k.startswith("module.") for k in wrapped.state_dict())
+    sink = net2.backbone._grad_sink
+    assert len(sink._buckets) >= 4 and sink.launched == 0
+
+
+def test_stepping_through_the_wrapper_matches_the_plain_driver():
+    import driver
+    from dasac_hip.parallel import OverlappedDataParallel
+    src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=6)
+    out = []
+    for wrap in (False, True):
+        cfg, net = _build()
+        optim = driver.make_optimizer(net, cfg)
+        step_net = OverlappedDataParallel(net, device_ids=[0]) if wrap else net
+        losses = []
+        for it in range(2):
+            t = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])
+            ls, lt, _ = driver.sac_train_iteration(step_net, optim, src, t, 2, it == 0, cfg.LR_TARGET)
+            losses.append((float(ls["loss_ce"]), float(lt["self_ce"])))
+        out.append((losses, {k: v.clone() for k, v in net.backbone.state_dict().items()}))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
+def _rank_main(rank, world, port, q, use_torch_ddp):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "da-sac_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import driver
+    from dasac_hip.parallel import OverlappedDataParallel
+    cfg, net = _build(seed=3 + rank)               # DIFFERENT initial weights per rank: construction must broadcast rank 0's
+    if rank == 1:
+        net.running_conf.fill_(0.5)                # and the buffers (also the ones exempt from the per-forward broadcast)
+        net.backbone.model.bn1.running_mean.add_(1.0)
+    if use_torch_ddp:
+        net.broadcast_frozen_buffers()             # stock DDP never sends the exempt buffers: the trainer does it once
+    optim = driver.make_optimizer(net, cfg)
+    if use_torch_ddp:
+        ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    else:
+        ddp = OverlappedDataParallel(net, device_ids=[0], bucket_mb=8)
+    src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=50 + rank)
+    losses = _two_passes(ddp, src, tgt, cfg.LR_TARGET)
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in net.backbone.named_parameters() if k in _PROBE}
+    optim.step()
+    torch.cuda.synchronize()
+    sd = net.backbone.state_dict()
+    sink = net.backbone._grad_sink
+    stats = None if sink is None else (len(sink._buckets), sink.launched, sink.launched_early)
+    q.put((rank, losses, {k: sd[k].detach().cpu().numpy() for k in _PROBE}, grads, stats,
+           float(sd["model.bn1.running_mean"].mean())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(use_torch_ddp):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, use_torch_ddp)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_two_ranks_overlapped_reduction_equals_the_manual_mean_and_stock_ddp():
+    import driver
+    got = _spawn(False)
+    # construction synchronised rank 1 to rank 0 (parameters, synced and exempt buffers); both ranks end up identical
+    assert got[0][5] == got[1][5]
+    for k in _PROBE:
+        assert (got[0][2][k] == got[1][2][k]).all(), k
+        assert (got[0][3][k] == got[1][3][k]).all(), k
+    # every bucket was reduced in both backward passes, all but the last of each pass BEFORE the backward ended
+    n_buckets, launched, early = got[0][4]
+    assert n_buckets >= 4 and launched == 2 * n_buckets and early >= 2 * (n_buckets - 1)
+    # one-process emulation: same start (rank 0's weights), per-rank data, gradients averaged by hand
+    cfg, net = _build(seed=3)
+    start = {k: v.clone() for k, v in net.state_dict().items()}
+    grads, losses = [], []
+    for rank in range(2):
+        net.load_state_dict(start)
+        src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=50 + rank)
+        losses.append(_two_passes(net, src, tgt, cfg.LR_TARGET))
+        grads.append({n: p.grad.clone() for n, p in net.backbone.named_parameters() if p.requires_grad})
+    for rank in range(2):
+        assert got[rank][1] == pytest.approx(losses[rank], rel=1e-5)
+    for k in _PROBE:
+        ref = ((grads[0][k] + grads[1][k]) / 2).cpu()
+        out = torch.from_numpy(got[0][3][k])
+        assert float((ref - out).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-12, k
+    # and the stock DistributedDataParallel wrapper over the same engine gives the same parameters after the step
+    stock = _spawn(True)
+    for k in _PROBE:
+        a, b = torch.from_numpy(got[0][2][k]), torch.from_numpy(stock[0][2][k])
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, k
