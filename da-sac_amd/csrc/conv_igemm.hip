@@ -30,6 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBK = 16;            // K-step of the forward/dgrad kernel
 constexpr int kThreads = 256;      // 4 waves
 constexpr int kInvalid = 1 << 20;  // dh of a padded table row: never in bounds
+constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
+constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8: the grid of every stream-K launch
 
 struct GemmGeom {
   // gathered tensor X [Nb, Cx, H, W]
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
   const __amdgpu_buffer_rsrc_t rsh = make_rsrc(ep.shift ? ep.shift : Out, ep.shift ? g.M * 4 : 0);
   const bool ragged = (g.M & 7) != 0;
   const __amdgpu_buffer_rsrc_t rpart = make_rsrc(STREAMK ? (const void*)partial : (const void*)Out,
-                                                 STREAMK ? (int)gridDim.x * ACC_REGS * kThreads * 4 : 0);
+                                                 STREAMK ? kSkWorkers * ACC_REGS * kThreads * 4 : 0);
 
   // ---- which part of the iteration space is mine --------------------------------------------
   // block b runs on XCD b%8: tiles (or ranges) that are adjacent -- same activation tile, next M tile --
@@ -173,13 +175,12 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
   int it, it_end;                                            // (tile, K-step) space: tiles*KT < 2^31 (checked by the host)
   int my_range = 0;
   long long sk_total = 0;
+  constexpr int G = kSkWorkers;                              // == gridDim.x of a stream-K launch; a constant divisor keeps the range arithmetic cheap
   if (STREAMK) {
-    const int G = gridDim.x;                                 // multiple of 8
     my_range = xcd * (G / kNumXcd) + slot;
-    const long long total = (long long)m_tiles * n_tiles * KT;
-    sk_total = total;
-    it = (int)(total * my_range / G);
-    it_end = (int)(total * (my_range + 1) / G);
+    sk_total = (long long)m_tiles * n_tiles * KT;
+    it = (int)(sk_total * my_range / G);
+    it_end = (int)(sk_total * (my_range + 1) / G);
   } else {
     // each XCD owns a CONTIGUOUS run of pixel tiles (spatial neighbours share halo rows in its L2)
     const int per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
@@ -336,8 +337,15 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
 #undef DASAC_STORE_TILE
 
     if (STREAMK) {
+      // Hand-off of a tile cut by range boundaries: the worker holding a tile's LATER K-steps deposits its accumulators in
+      // `partial` and raises a flag, the worker holding the FIRST K-steps (the owner) adds the deposits and runs the epilogue.
+      // Deposits are agent-scope (sc1) write-through stores read back with sc1 loads -- placement independent (the per-XCD
+      // L2s are not coherent with each other), no buffer_wbl2 / buffer_inv fences.  (Measured in round 3: routing the
+      // deposits of same-XCD neighbours through L2 with plain accesses instead -- whole tiles per XCD, hardware XCC id
+      // checked -- changes nothing: 116.2 vs 113.2 us on the layer3 3x3 remainder.  The ~25 us a remainder launch costs
+      // beyond its K-steps is ramp, hand-off latency and epilogue, not the 2 x 50 MB of deposit traffic.)
+      constexpr int kAux = kAuxSc1;
       if (ks > 0) {
-        // I hold the LAST K-steps of a tile that starts in the previous range: deposit and move on.
         // partial layout [range][32x32 sub-tile][quarter][thread][4]: 16-byte stores, a wave writes 1 KB contiguous
         const int dst0 = my_range * (ACC_REGS * kThreads * 4);     // bytes; scalar
 #pragma unroll
@@ -349,52 +357,58 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
               __builtin_amdgcn_raw_buffer_store_b128(
                   u32x4{__float_as_uint(acc[i][j][4 * r4]), __float_as_uint(acc[i][j][4 * r4 + 1]), __float_as_uint(acc[i][j][4 * r4 + 2]),
                         __float_as_uint(acc[i][j][4 * r4 + 3])},
-                  rpart, (unsigned)t * 16u, dst0 + ((i * TN + j) * 4 + r4) * kThreads * 16, kAuxSc1);
+                  rpart, (unsigned)t * 16u, dst0 + ((i * TN + j) * 4 + r4) * kThreads * 16, kAux);
             asm volatile("" ::: "memory");
           }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's write-through stores have left
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's stores are acknowledged (L2 / memory)
         __syncthreads();
         if (t == 0) __hip_atomic_store(&flags[my_range], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (ke < KT) {
-        // I hold the FIRST K-steps; the rest was deposited by the following range(s), each at the very start of
-        // its work (a range shorter than a tile -- fewer tiles than workers -- makes several of them contribute).
-        const int G = gridDim.x;
+        // I hold the FIRST K-steps; the rest was deposited by the following range(s), each at the very start of its work
+        // (a range shorter than a tile -- fewer tiles than workers -- makes several of them contribute).  Ranges are never
+        // empty (the host picks this schedule only with >= 1 K-step per worker).
         const long long tile_end = (long long)(tile + 1) * KT;
-        for (int r = my_range + 1; r < G; ++r) {
-          const long long r_begin = sk_total * r / G, r_end = sk_total * (r + 1) / G;
-          if (r_end > r_begin) {                               // an empty range deposits nothing
-            if (t == 0) {
-              // Progress does not need all workers resident: a range deposits at the very START of its work, before it
-              // waits for anything, and blocks are dispatched in id order, so the depositor of r is at worst the next
-              // block to get a slot.  A wait that still outlasts ~2^26 sleeps (seconds) means the depositor died:
-              // abort the kernel (the stream reports a launch failure) instead of summing a slot that was never written.
-              int spins = 0;
-              while (__hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins >= (1 << 26)) __builtin_trap();
-              }
-              // self-cleaning flags: a range deposits at most once per launch and this worker is its only consumer,
-              // so the flag can go back to 0 right here -- the next launch on the stream finds the array zeroed and
-              // no memset (an extra kernel + two launch gaps per conv) is needed
-              __hip_atomic_store(&flags[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int n_contrib = 1;                                     // contributors are my_range + 1 .. my_range + n_contrib
+        while (sk_total * (my_range + n_contrib + 1) / G < tile_end) ++n_contrib;
+        if (t == 0) {
+          // Progress does not need all workers resident: a range deposits at the very START of its work, before it waits for
+          // anything, and blocks are dispatched in id order, so the depositor of r is at worst the next block to get a slot.
+          // A wait that still outlasts ~2^26 sleeps (seconds) means the depositor died: abort the kernel (the stream reports
+          // a launch failure) instead of summing a slot that was never written.  ALL flags are collected before the first
+          // load: the depositors reach their boundaries together, so this costs one wait, not one per contributor.
+          for (int r = my_range + 1; r <= my_range + n_contrib; ++r) {
+            int spins = 0;
+            while (__hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins >= (1 << 26)) __builtin_trap();
             }
-            __syncthreads();
-            const int src0 = r * (ACC_REGS * kThreads * 4);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                f32x4 pv[4];                                   // one sub-tile of the deposit: four 16-byte loads in flight
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) pv[r4] = buf_f32x4_sc1(rpart, (unsigned)t * 16u, src0 + ((i * TN + j) * 4 + r4) * kThreads * 16);
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += pv[r4][e];
-                asm volatile("" ::: "memory");
-              }
+            // self-cleaning flags: a range deposits at most once per launch and this worker is its only consumer, so the
+            // flag can go back to 0 right here -- the next launch on the stream finds the array zeroed (no memset per conv)
+            __hip_atomic_store(&flags[r], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if (r_end >= tile_end) break;                        // that range reached the end of my tile
+        }
+        __syncthreads();
+        for (int r = my_range + 1; r <= my_range + n_contrib; ++r) {
+          const int src0 = r * (ACC_REGS * kThreads * 4);
+          // half a deposit in flight at a time: 8 x 16-byte loads per thread (a whole one -- 64 more registers next to the 64
+          // accumulators -- does not fit the 168 registers of 3 workers per CU without spilling)
+          constexpr int QH = TM * TN * 2;
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {
+            f32x4 pv[QH];
+#pragma unroll
+            for (int q = 0; q < QH; ++q) {
+              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rpart, (unsigned)t * 16u, src0 + (hb * QH + q) * kThreads * 16, kAux);
+              pv[q] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            }
+#pragma unroll
+            for (int q = 0; q < QH; ++q) {
+              const int qq = hb * QH + q, sub = qq >> 2, r4 = qq & 3;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[sub / TN][sub % TN][4 * r4 + e] += pv[q][e];
+            }
+            asm volatile("" ::: "memory");
+          }
         }
       }
     }
@@ -899,41 +913,71 @@ __device__ __forceinline__ float sum_splits(const float* __restrict__ p, size_t 
   return (g0 + g1) + (g2 + g3);
 }
 
-// dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G)
-// grid (chunks of 1024 k, output channels); the dot term is combined with one float atomic per block.
+// dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G);  sum_dz[co] = sum_s Psum[s][co]
+// grid (chunks of 64 input channels, output channels), 256 threads = 64 channels x 4 split lanes.  A thread adds the splits
+// s = lane, lane + 4, ... of up to 9 taps of ITS channel (9 independent, coalesced slab loads in flight per step); the four
+// lanes meet in LDS and the block writes its 64 x taps gradients in dW's own order -- one contiguous run per block, where the
+// tap-major slab order would touch every 36-byte [ci] group of a 3x3 layer nine times from nine places.  The dot term is
+// combined with one float atomic per block.
+constexpr int kWrTaps = 9;
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P, const float* __restrict__ Psum, int splits,
                                                     int Mpad, int Kpad, const float* __restrict__ Wt,
                                                     const float* __restrict__ scale, float* __restrict__ dW,
                                                     float* __restrict__ dot, float* __restrict__ sum_dz, int Cin, int taps,
-                                                    int tap0) {
+                                                    int tap0, int flat_cin) {
+  // flat_cin > 0 (few input channels: the stem, VGG's first conv): the caller passes Cin = true Cin * taps and taps = 1, the
+  // 64 channel lanes then run along the slab's whole k axis (a 3-channel layer would use 3 of them); dW's index is remapped.
   const int co = blockIdx.y;
-  if (sum_dz && blockIdx.x == 0 && threadIdx.x == 0) {
+  const int tx = threadIdx.x, c = tx & 63, q = tx >> 6;
+  if (sum_dz && blockIdx.x == 0 && q == 0) {                 // one wave: the splits' channel sums in parallel
     float sv = 0.f;
-    for (int s = 0; s < splits; ++s) sv += Psum[(size_t)s * Mpad + co];
-    sum_dz[co] = sv;
+    for (int s2 = c; s2 < splits; s2 += 64) sv += Psum[(size_t)s2 * Mpad + co];
+    sv = wave_sum(sv);
+    if (c == 0) sum_dz[co] = sv;
   }
-  const int n = Cin * taps;
+  __shared__ float red[4][kWrTaps][64];
+  const int ci0 = blockIdx.x * 64, ci = ci0 + c;
   const float sc = scale ? scale[co] : 1.f;
   const size_t slab = (size_t)Mpad * Kpad;
   float part = 0.f;
+  for (int tb = 0; tb < taps; tb += kWrTaps) {
+    const int nt = min(kWrTaps, taps - tb);
+    float acc[kWrTaps];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = blockIdx.x * 1024 + u * 256 + threadIdx.x;   // packed order (tap-major): coalesced slab reads
-    if (i < n) {
-      const int tap = i / Cin, ci = i - tap * Cin;
-      const size_t kidx = (size_t)co * Kpad + (size_t)(tap0 + tap) * Cin + ci;
-      const float gsum = sum_splits(P + kidx, slab, splits);
-      const size_t widx = ((size_t)co * Cin + ci) * taps + tap;
-      if (dot) part += gsum * Wt[widx];
-      dW[widx] = gsum * sc;
+    for (int u = 0; u < kWrTaps; ++u) acc[u] = 0.f;
+    if (ci < Cin) {
+      const float* p0 = P + (size_t)co * Kpad + (size_t)(tap0 + tb) * Cin + ci;
+      for (int s2 = q; s2 < splits; s2 += 4) {
+        const float* ps = p0 + (size_t)s2 * slab;
+#pragma unroll
+        for (int u = 0; u < kWrTaps; ++u)
+          if (u < nt) acc[u] += ps[(size_t)u * Cin];
+      }
     }
+#pragma unroll
+    for (int u = 0; u < kWrTaps; ++u) red[q][u][c] = acc[u];
+    __syncthreads();
+    for (int e = tx; e < 64 * nt; e += 256) {                // (channel, tap) pairs in dW order
+      const int c2 = e / nt, u2 = e - c2 * nt;
+      if (ci0 + c2 < Cin) {
+        const float gsum = (red[0][u2][c2] + red[1][u2][c2]) + (red[2][u2][c2] + red[3][u2][c2]);
+        size_t widx = ((size_t)co * Cin + ci0 + c2) * taps + tb + u2;
+        if (flat_cin > 0) {                                    // k = tap * Cin_true + ci  ->  [co][ci][tap]
+          const int k = ci0 + c2, tap = k / flat_cin, ci_t = k - tap * flat_cin;
+          widx = ((size_t)co * flat_cin + ci_t) * (Cin / flat_cin) + tap;
+        }
+        if (dot) part += gsum * Wt[widx];
+        dW[widx] = gsum * sc;
+      }
+    }
+    __syncthreads();
   }
   if (dot) {
-    __shared__ float red[4];
+    __shared__ float redd[4];
     part = wave_sum(part);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    if (c == 0) redd[q] = part;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&dot[co], red[0] + red[1] + red[2] + red[3]);
+    if (tx == 0) atomicAdd(&dot[co], (redd[0] + redd[1]) + (redd[2] + redd[3]));
   }
 }
 
@@ -956,8 +1000,6 @@ static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, 
   return DASAC_OK;
 }
 
-constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
-constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8
 
 // stream-K pays when the tile count leaves the last round of resident blocks mostly empty.
 // The persistent grid (3 workers per CU x 256 CUs) and the XCD mapping are sized for the full MI355X; a device with
@@ -1287,8 +1329,13 @@ extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, in
   const int bm = pick_bm(Mpad);
   const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, bm, (M % 8 == 0 && bm != 32) ? wgrad_bn(Cin) : 128);
   const float* P = reinterpret_cast<const float*>(workspace);
-  hipLaunchKernelGGL(wgrad_reduce, dim3((Cin * taps + 1023) / 1024, M), dim3(256), 0, as_stream(stream), P,
-                     P + (size_t)splits * Mpad * Kpad, splits, Mpad, Kpad, w, scale, dw, dot, sum_dz, Cin, taps, tap0);
+  const float* Psum = P + (size_t)splits * Mpad * Kpad;
+  if (Cin < 32)      // lanes along the whole k axis (see the kernel); tap0 * Cin is this branch's first k
+    hipLaunchKernelGGL(wgrad_reduce, dim3((Cin * taps + 63) / 64, M), dim3(256), 0, as_stream(stream), P + (size_t)tap0 * Cin, Psum,
+                       splits, Mpad, Kpad, w, scale, dw, dot, sum_dz, Cin * taps, 1, 0, Cin);
+  else
+    hipLaunchKernelGGL(wgrad_reduce, dim3((Cin + 63) / 64, M), dim3(256), 0, as_stream(stream), P, Psum, splits, Mpad, Kpad, w, scale,
+                       dw, dot, sum_dz, Cin, taps, tap0, 0);
   DASAC_CHECK_LAUNCH("wgrad_reduce");
   return DASAC_OK;
 }

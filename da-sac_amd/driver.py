@@ -6,15 +6,52 @@ import torch
 
 
 def make_optimizer(net, cfg_model, fused=True):
-    """SGD(momentum, no nesterov) over the model's four parameter groups (base_trainer.py:63-66): the fused
-    multi-tensor HIP optimiser (same update rule / state layout) or, with fused=False, torch.optim.SGD itself."""
+    """`BaseTrainer.get_optim` (base_trainer.py:47-73) over the model's four parameter groups (train.py:93-96):
+      OPT == "SGD" (the default, configs/*.yaml): SGD(momentum, nesterov=OPT_NESTEROV) -- the fused multi-tensor HIP optimiser
+          (same update rule / state layout; plain momentum only) or, with fused=False / nesterov, torch.optim.SGD itself;
+      OPT == "Adam": torch.optim.Adam(lr, betas=(BETA1, 0.999), weight_decay) (base_trainer.py:57-61);
+      any other name in torch.optim: optim(params, lr=LR) (base_trainer.py:68-69); unknown names raise NotImplementedError.
+    Every group carries its own lr / weight_decay (basenet.py:102-139), so the keyword defaults below only fill the gaps,
+    exactly as in the reference."""
     core = net.module if hasattr(net, "module") else net
     groups = core.parameter_groups(cfg_model.LR, cfg_model.WEIGHT_DECAY)
-    nesterov = getattr(cfg_model, "OPT_NESTEROV", False)
-    if fused and not nesterov:
-        from dasac_hip.optim import FusedSGD
-        return FusedSGD(groups, momentum=cfg_model.MOMENTUM)
-    return torch.optim.SGD(groups, momentum=cfg_model.MOMENTUM, nesterov=nesterov)
+    opt = getattr(cfg_model, "OPT", "SGD")
+    if not hasattr(torch.optim, opt):
+        print("Optimiser {} not supported".format(opt))
+        raise NotImplementedError
+    if opt == "Adam":
+        upd = torch.optim.Adam(groups, lr=cfg_model.LR, betas=(getattr(cfg_model, "BETA1", 0.5), 0.999), weight_decay=cfg_model.WEIGHT_DECAY)
+    elif opt == "SGD":
+        nesterov = getattr(cfg_model, "OPT_NESTEROV", False)
+        if fused and not nesterov:
+            from dasac_hip.optim import FusedSGD
+            upd = FusedSGD(groups, lr=cfg_model.LR, momentum=cfg_model.MOMENTUM, weight_decay=cfg_model.WEIGHT_DECAY)
+        else:
+            upd = torch.optim.SGD(groups, lr=cfg_model.LR, momentum=cfg_model.MOMENTUM, nesterov=nesterov, weight_decay=cfg_model.WEIGHT_DECAY)
+    else:
+        upd = getattr(torch.optim, opt)(groups, lr=cfg_model.LR)
+    upd.zero_grad()
+    return upd
+
+
+def train_epoch(net, optim, loader_source, loader_target, cfg_model, group_size, target_only=False, on_iteration=None):
+    """The loop body of `Trainer.train_epoch` (train.py:266-298) -- the per-iteration POLICY around the two step functions:
+    baseline mode runs the source step and the no-grad target forward (AdaBN, :281-289); SAC mode refreshes the momentum
+    teacher on every NET_MOMENTUM_ITER-th iteration of the epoch (`update_teacher = i % NET_MOMENTUM_ITER == 0`, :294), skips
+    the source pass under TRAIN.TARGET_ONLY (:274-276).  Batches are what the reference's loaders yield, already on the device:
+    (image, masks_gt) and (frames1, frames_gt, frames2, affine, affine_inv).  Returns the number of iterations."""
+    n = 0
+    for i, (batch_source, batch_target) in enumerate(zip(loader_source, loader_target)):
+        if cfg_model.BASELINE:
+            out = (baseline_train_iteration(net, optim, batch_source, batch_target[0]), None, None)
+        else:
+            update_teacher = i % cfg_model.NET_MOMENTUM_ITER == 0
+            out = sac_train_iteration(net, optim, batch_source, batch_target, group_size, update_teacher, cfg_model.LR_TARGET,
+                                      target_only=target_only)
+        if on_iteration is not None:
+            on_iteration(i, out)
+        n = i + 1
+    return n
 
 
 def _dist_state(rank, world):

@@ -95,3 +95,46 @@ def test_infer_label_maps_through_the_model():
         _, up = net(x, teacher=False)
     want = torch.tensor(driver.CITYSCAPES_TRAIN_TO_ID, device="cuda")[up.softmax(1).argmax(1)]
     assert float((lab.long() != want).float().mean()) < 1e-3
+
+
+def test_make_optimizer_follows_get_optim():
+    """base_trainer.py:47-73: SGD (fused or torch's), Adam with betas=(BETA1, .999), any other torch.optim name with lr only,
+    NotImplementedError for names torch.optim does not have; the four parameter groups keep their own lr / weight decay."""
+    import models
+    import driver
+    from dasac_hip.optim import FusedSGD
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False))
+    net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT)
+    net.train()
+    sgd = driver.make_optimizer(net, cfg)
+    assert isinstance(sgd, FusedSGD) and [g["lr"] for g in sgd.param_groups] == pytest.approx([2.5e-4, 5e-4, 2.5e-3, 5e-3])
+    assert [g["weight_decay"] for g in sgd.param_groups] == [5e-4, 0.0, 5e-4, 0.0] and sgd.param_groups[0]["momentum"] == 0.9
+    nes = driver.make_optimizer(net, NS(**dict(vars(cfg), OPT_NESTEROV=True)))
+    assert type(nes) is torch.optim.SGD and nes.param_groups[0]["nesterov"]
+    adam = driver.make_optimizer(net, NS(**dict(vars(cfg), OPT="Adam", BETA1=0.5)))
+    assert type(adam) is torch.optim.Adam and adam.param_groups[0]["betas"] == (0.5, 0.999)
+    assert [g["lr"] for g in adam.param_groups] == pytest.approx([2.5e-4, 5e-4, 2.5e-3, 5e-3])
+    rms = driver.make_optimizer(net, NS(**dict(vars(cfg), OPT="RMSprop")))
+    assert type(rms) is torch.optim.RMSprop
+    with pytest.raises(NotImplementedError):
+        driver.make_optimizer(net, NS(**dict(vars(cfg), OPT="NoSuchOptimiser")))
+
+
+def test_train_epoch_policy(monkeypatch):
+    """train.py:266-298: the teacher is refreshed on every NET_MOMENTUM_ITER-th iteration of an epoch, TARGET_ONLY is passed
+    through, baseline mode takes the AdaBN path."""
+    import driver
+    calls = []
+    monkeypatch.setattr(driver, "sac_train_iteration",
+                        lambda net, optim, s, t, L, upd, lr_t, target_only=False: calls.append(("sac", s, t, L, upd, lr_t, target_only)))
+    monkeypatch.setattr(driver, "baseline_train_iteration", lambda net, optim, s, t: calls.append(("base", s, t)))
+    cfg = NS(**dict(DEFAULT_CFG, NET_MOMENTUM_ITER=3))
+    src, tgt = [("s%d" % i,) for i in range(7)], [("t%d" % i,) for i in range(7)]
+    seen = []
+    n = driver.train_epoch(None, None, src, tgt, cfg, 4, target_only=True, on_iteration=lambda i, out: seen.append(i))
+    assert n == 7 and seen == list(range(7))
+    assert [c[4] for c in calls] == [True, False, False, True, False, False, True]
+    assert all(c[0] == "sac" and c[3] == 4 and c[5] == 5.0 and c[6] is True for c in calls)
+    calls.clear()
+    driver.train_epoch(None, None, src[:2], tgt[:2], NS(**dict(DEFAULT_CFG, BASELINE=True)), 1)
+    assert calls == [("base", ("s0",), "t0"), ("base", ("s1",), "t1")]

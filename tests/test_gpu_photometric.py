@@ -77,3 +77,26 @@ def test_make_returns_augmented_student_frames_and_clean_teacher_frames():
     assert not torch.equal(f1, f2)
     with pytest.raises(Exception):
         tv.augment(u8[:, :2], None, photo)
+
+
+def test_color_jitter_all_24_orders_bit_exact():
+    """Every permutation of (brightness, contrast, saturation, hue) through the device pipeline vs the oracle (which
+    tests/test_photometric_cpu.py pins against Pillow for the same 24 orders): whatever order torchvision's RNG draws
+    (/root/reference/datasets/tf_target.py:365-390, torchvision absent and unversioned here), the pixels are covered."""
+    import itertools
+    import views
+    H, W = 45, 67
+    gen = np.random.RandomState(12)
+    orders = list(itertools.permutations(range(4)))
+    img = gen.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    img[:9, :20] = (255, 0, 7)
+    for chunk in range(2):                                            # the kernel takes up to 16 views per call
+        part = orders[chunk * 12:(chunk + 1) * 12]
+        photo = [dict(blur=None if i % 3 else 1.1, grey=False,
+                      jitter=(list(o), [float(gen.uniform(0.6, 1.4)), float(gen.uniform(0.6, 1.4)), float(gen.uniform(0.6, 1.4)), float(gen.uniform(-0.1, 0.1))]))
+                 for i, o in enumerate(part)]
+        tv = views.TargetViews((H, W), len(part))
+        u8 = _planar(np.stack([img] * len(part))).cuda()
+        _, out = tv.augment(u8, None, photo, want_u8=True)
+        want = np.stack([P.photometric_u8(img, p) for p in photo])
+        assert torch.equal(out.cpu(), _planar(want)), chunk

@@ -3,7 +3,8 @@ assembly (no GPU needed, ~10 s) and checks that
   * the tile-per-block forward/dgrad kernel stays at <= 128 VGPRs (4 waves per SIMD) and the persistent stream-K variant and
     the weight-gradient kernel at <= 168 (3 waves per SIMD),
   * NO scratch (spill) instruction sits between the first and the last MFMA of any of them -- i.e. inside the K loop; the few
-    spilled values of the forward kernel (tile-index bookkeeping) are written in the prologue and re-read in the epilogue."""
+    spilled values of the forward kernel (tile-index bookkeeping) are written in the prologue and re-read in the epilogue,
+    those of the stream-K variant sit around the tile hand-off."""
 import os
 import re
 import shutil
@@ -41,4 +42,7 @@ def test_hot_gemm_loops_have_no_scratch_and_fit_their_occupancy(tmp_path):
         assert len(mfma) >= 32
         inside = [l.strip() for l in body[mfma[0]:mfma[-1]] if "scratch_" in l]
         assert not inside, (key, inside[:3])
-        assert scratch <= 64, (key, scratch)
+        # bytes of scratch per lane.  The persistent stream-K variant may park up to 48 values around the tile hand-off (once per
+        # tile cut by a range boundary: half a deposit, 32 registers, is in flight next to the 64 accumulators); everything else
+        # keeps the round-1 budget of a few prologue values.
+        assert scratch <= (192 if "ELb1ELb1ELb0EEE" in key else 64), (key, scratch)

@@ -100,3 +100,37 @@ def test_product_parameter_rows():
     rows = product.photometric_params(vs)
     assert rows.shape == (2, 12) and rows.dtype == np.float64
     assert rows[0].tolist() == [1.25, 1.0, 2, 0, 3, 1, 0.9, 1.1, 1.3, -0.05, 1.0, 0.0] and not rows[1].any()
+
+
+def test_color_jitter_oracle_equals_pillow_for_all_24_adjustment_orders():
+    """torchvision's ColorJitter applies brightness / contrast / saturation / hue in a randomly permuted order
+    (/root/reference/datasets/tf_target.py:365-390).  torchvision is absent here, so WHICH permutation its RNG stream yields for a
+    seed is not pinned -- instead every one of the 24 orders is: the oracle's chain equals the real Pillow chain for each."""
+    import itertools
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageEnhance
+    rs = np.random.RandomState(7)
+    img = rs.randint(0, 256, (29, 41, 3)).astype(np.uint8)
+    img[:8, :12] = (250, 3, 128)
+
+    def pillow_adjust(pim, which, f):
+        if which == 0:
+            return ImageEnhance.Brightness(pim).enhance(f)
+        if which == 1:
+            return ImageEnhance.Contrast(pim).enhance(f)
+        if which == 2:
+            return ImageEnhance.Color(pim).enhance(f)
+        h, s, v = pim.convert("HSV").split()
+        np_h = np.array(h, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            np_h += np.int32(f * 255).astype(np.uint8)
+        return Image.merge("HSV", (Image.fromarray(np_h, "L"), s, v)).convert("RGB")
+
+    orders = list(itertools.permutations(range(4)))
+    assert len(orders) == 24
+    for order in orders:
+        factors = [float(rs.uniform(0.6, 1.4)), float(rs.uniform(0.6, 1.4)), float(rs.uniform(0.6, 1.4)), float(rs.uniform(-0.1, 0.1))]
+        pim = Image.fromarray(img, "RGB")
+        for which in order:
+            pim = pillow_adjust(pim, which, factors[which])
+        assert np.array_equal(np.asarray(pim), P.color_jitter(img, list(order), factors)), order
