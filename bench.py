@@ -95,8 +95,8 @@ def cpu_baseline_entry(size, dt, cores):
                       "SAC head, SGD) = {1:.1f} s on {2} threads; 1 source image per sample".format(size, dt, cores)}
 
 
-def hip_sample(size, sd, device):
-    """The same sample through the HIP module (fresh model, the oracle's weights and inputs)."""
+def hip_sample(size, sd, device, fuse=True):
+    """The same sample through the HIP module (fresh model, the oracle's weights and inputs); fuse: the student schedule."""
     import models
     import driver
     cfg = model_cfg()
@@ -110,7 +110,8 @@ def hip_sample(size, sd, device):
     src, tgt = _sample_inputs(size)
     to = lambda ts: tuple(t.to(device) for t in ts)
     # sum_grads_in_optimizer=False: .grad holds source + target gradients after the step, like the reference's
-    ls, lt, outs = driver.sac_train_iteration(net, optim, to(src), to(tgt), 1, False, cfg.LR_TARGET, sum_grads_in_optimizer=False)
+    ls, lt, outs = driver.sac_train_iteration(net, optim, to(src), to(tgt), 1, False, cfg.LR_TARGET, sum_grads_in_optimizer=False,
+                                              fuse_passes=fuse)
     torch.cuda.synchronize(device)
     named = dict(net.backbone.named_parameters())
     return {"loss_ce": float(ls["loss_ce"]), "self_ce": float(lt["self_ce"]), "teacher_diff": float(lt["teacher_diff"]),
@@ -133,12 +134,12 @@ def compare_sample(ref, got):
             "sampled_tensors": len(_PARITY_KEYS)}
 
 
-def parity_fullres(size, device=None, sample=None):
+def parity_fullres(size, device=None, sample=None, fuse=True):
     """(timing of the oracle, comparison dict) of the 1 source + 1 target crop sample at size x size."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     dt, cores, sd, ref = cpu_sample(size) if sample is None else sample
-    cmp_ = compare_sample(ref, hip_sample(size, sd, device))
-    cmp_["size"] = size
+    cmp_ = compare_sample(ref, hip_sample(size, sd, device, fuse))
+    cmp_["size"], cmp_["student_schedule"] = size, "fused" if fuse else "two passes"
     return (dt, cores), cmp_
 
 
@@ -173,6 +174,9 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="arithmetic of the forward/data-gradient GEMMs: exact fp32 MFMA (default, the reference's arithmetic) or the "
                          "opt-in split-bf16 path (3 bf16 MFMAs per product, fp32 accumulate)")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="run the student's source and target passes one after the other (the reference's call order, train.py:266-298) "
+                         "instead of once over the concatenated batch (SAC.forward_fused: same gradient sum, see DESIGN 5)")
     ap.add_argument("--alt", action="store_true", help="also run the steps once in the other precision (reported as \"alt\", no credit)")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"],
                     help="cfg3 (default, the headline): RN101+SAC 8+2x4 crops @769^2; cfg2: RN101 baseline/AdaBN step, 2 source + 2 "
@@ -242,13 +246,15 @@ def main():
         driver.calibrate_classifier(net, src[0][:1])          # logits std ~3 whatever the backbone's feature scale
     src = (src[0], driver.self_consistent_labels(net, src[0]))
 
+    schedule = {"fuse": not args.two_pass}
+
     def step(i):
         if baseline:      # train.py:274-289: source fwd/bwd/step + no-grad train-mode target forward (AdaBN)
             l = driver.baseline_train_iteration(step_net, optim, src, tgt[0])
             return None, l, None
         tgt_i = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])      # forward rewrites -1 -> 255 in place
         return driver.sac_train_iteration(step_net, optim, src, tgt_i, args.views, update_teacher=(i == 0),
-                                          lr_target=cfg.LR_TARGET)
+                                          lr_target=cfg.LR_TARGET, fuse_passes=schedule["fuse"])
 
     def fence():
         if world > 1:
@@ -297,6 +303,18 @@ def main():
     if not args.no_kernel_table:
         dt_prof, prof, _ = measure(done, 0, psteps, True)
         done += psteps
+    # 3) the other student schedule (two passes <-> one fused pass), a few steps, for the record
+    other_sched = None
+    if not baseline and wrapper != "ddp" and not args.no_kernel_table:
+        schedule["fuse"] = not schedule["fuse"]
+        try:
+            dt3, _, _ = measure(done, 1, psteps, False)
+            other_sched = round(dt3 / psteps * 1e3, 3)
+        except Exception as exc:
+            other_sched = repr(exc)[:200]
+        schedule["fuse"] = not schedule["fuse"]
+        done += 1 + psteps
+    fused_now = bool(schedule["fuse"]) and not baseline and wrapper != "ddp"
     alt = None
     if args.alt and not baseline:
         # the same K steps once more in the other arithmetic (outside the contract's timed region; reported as "alt")
@@ -338,6 +356,9 @@ def main():
                                             "p=0.1, random-init weights"}[args.config].format(args.batch, args.groups, args.views, hw[0], hw[1]),
                        "global_batch": world * args.batch, "crops_per_step": world * (args.batch + args.groups * args.views),
                        "parallelism": "dp{}".format(world),
+                       "student_schedule": ("fused: source + target crops in ONE student pass and ONE backward over loss_ce + LR_TARGET*self_ce "
+                                            "(same weights, frozen BN, teacher independent: the gradient sum of train.py:266-298's two passes)"
+                                            if fused_now else "two passes (train.py:266-298 call order)"),
                        "distributed": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                                        "backend": dist.get_backend() if dist.is_initialized() else None, "wrapper": wrapper,
                                        "ranks_per_gpu": per_gpu, "self_launched": os.environ.get("DASAC_BENCH_SELF_LAUNCHED") == "1"},
@@ -356,6 +377,7 @@ def main():
                          "launches": dom["launches"], "avg_launch_ms": round(dom["seconds"] / max(dom["launches"], 1) * 1e3, 4),
                          "measured_in": "second pass of {} steps with a HIP event pair around each launch (not the headline's timed region)".format(psteps)},
             "ms_per_step_instrumented": None if dt_prof is None else round(dt_prof / psteps * 1e3, 3),
+            "ms_per_step_other_schedule": {("two_pass" if fused_now else "fused"): other_sched},
             "kernels": kernel_table(prof, psteps),
             "check": {"loss_ce": losses.get("loss_ce"), "self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"),
                       "labelled_frac": round(labelled, 4)},
@@ -374,7 +396,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "failed: " + repr(exc)[:160]}
             if sample is not None:
                 try:
-                    line["parity_fullres"] = parity_fullres(args.size, dev, sample)[1]
+                    line["parity_fullres"] = parity_fullres(args.size, dev, sample, fuse=fused_now)[1]
                 except Exception as exc:
                     line["parity_fullres"] = {"error": repr(exc)[:200]}
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -883,6 +883,42 @@ __global__ void pack_weights(const float* __restrict__ Wt, const float* __restri
   }
 }
 
+// All (single-branch) convolutions of a network in ONE launch: job j describes one packed operand (forward or data-gradient
+// layout of one layer), chunk (j, c) covers kPackChunk consecutive floats of its output -- the K padding rows and the M padding
+// columns are written as zeros here, so no memset per layer either.  Replaces ~2 x 104 pack_weights launches per optimiser step.
+constexpr int kPackChunk = 256 * 32;
+__global__ __launch_bounds__(256) void pack_weights_multi(const dasac_pack_job* __restrict__ jobs, const int2* __restrict__ chunks) {
+  const int2 ch = chunks[blockIdx.x];
+  const dasac_pack_job jb = jobs[ch.x];
+  const int C = jb.mode == 0 ? jb.Cin : jb.Cout;
+  const int K = jb.taps * C;
+  const int64_t total = (int64_t)jb.Kpad * jb.Mpad;
+  const int64_t base = (int64_t)ch.y * kPackChunk;
+  const int row4 = jb.Mpad * 4;
+#pragma unroll 4
+  for (int u = 0; u < kPackChunk / 256; ++u) {
+    const int64_t j = base + u * 256 + threadIdx.x;             // == offset in the packed operand [(k/4)][Mpad][4]
+    if (j >= total) break;
+    const int kq = (int)(j / row4), rem = (int)(j - (int64_t)kq * row4);
+    const int m = rem >> 2, k = kq * 4 + (rem & 3);
+    float v = 0.f;
+    if (k < K) {
+      int tap, c;
+      decode_k(k, C, jb.taps, jb.order, tap, c);
+      if (jb.mode == 0) {
+        if (m < jb.Cout) {
+          v = jb.w[((int64_t)m * jb.Cin + c) * jb.taps + tap];
+          if (jb.scale) v = v * jb.scale[m];
+        }
+      } else if (m < jb.Cin) {
+        v = jb.w[((int64_t)c * jb.Cin + m) * jb.taps + tap];
+        if (jb.scale) v = v * jb.scale[c];
+      }
+    }
+    jb.out[j] = v;
+  }
+}
+
 // fp32 packed weights [(k/4)][Mpad][4] -> split-bf16 operands: K-step t (16 k) holds four slots of Mpad
 // 16-byte words, slot 2*o + h = octet o (k = 16t + 8o .. +7), h = 0 heads / 1 tails -- the same addressing
 // as the fp32 tile (slot == quad), so conv_gemm's weight path is shared.
@@ -1113,6 +1149,15 @@ extern "C" int dasac_conv_pack(const float* w, const float* scale, int Cout, int
   hipLaunchKernelGGL(pack_weights, dim3(stream_grid(total, 256)), dim3(256), 0, s, w, scale, packed, Cout, Cin, taps, tap0,
                      total_taps, Mpad, transposed ? 1 : 0, order);
   DASAC_CHECK_LAUNCH("pack_weights");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_pack_chunk_elems(void) { return kPackChunk; }
+
+extern "C" int dasac_conv_pack_multi(const dasac_pack_job* jobs, const int32_t* chunks, int n_chunks, dasac_stream_t stream) {
+  DASAC_REQUIRE(jobs && chunks && n_chunks > 0, "conv_pack_multi: bad arguments");
+  hipLaunchKernelGGL(pack_weights_multi, dim3(n_chunks), dim3(256), 0, as_stream(stream), jobs, reinterpret_cast<const int2*>(chunks));
+  DASAC_CHECK_LAUNCH("pack_weights_multi");
   return DASAC_OK;
 }
 

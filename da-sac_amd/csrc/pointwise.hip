@@ -19,6 +19,20 @@ __global__ void bn_fold(const float* __restrict__ gamma, const float* __restrict
   if (invstd) invstd[c] = is;
 }
 
+// every frozen BN of a network in one launch: chunk (j, c) = 256 channels of job j
+__global__ __launch_bounds__(256) void bn_fold_multi(const dasac_fold_job* __restrict__ jobs, const int2* __restrict__ chunks) {
+  const int2 ch = chunks[blockIdx.x];
+  const dasac_fold_job jb = jobs[ch.x];
+  const int c = ch.y * 256 + threadIdx.x;
+  if (c >= jb.C) return;
+  const float is = 1.f / sqrtf(jb.var[c] + jb.eps);
+  const float a = jb.gamma[c] * is;
+  const float m = jb.conv_bias ? jb.mean[c] - jb.conv_bias[c] : jb.mean[c];
+  jb.scale[c] = a;
+  jb.shift[c] = jb.beta[c] - m * a;
+  jb.invstd[c] = is;
+}
+
 // dgamma = invstd*(dot + (b - mean)*sum_dz), dbeta = sum_dz, dbias_conv = scale*sum_dz
 __global__ void bn_param_grads(const float* __restrict__ dot, const float* __restrict__ sum_dz, const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ scale,
@@ -253,6 +267,13 @@ extern "C" int dasac_bn_fold(const float* gamma, const float* beta, const float*
   hipLaunchKernelGGL(bn_fold, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta, mean, var, conv_bias, eps, C,
                      scale, shift, invstd);
   DASAC_CHECK_LAUNCH("bn_fold");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_fold_multi(const dasac_fold_job* jobs, const int32_t* chunks, int n_chunks, dasac_stream_t stream) {
+  DASAC_REQUIRE(jobs && chunks && n_chunks > 0, "bn_fold_multi: bad arguments");
+  hipLaunchKernelGGL(bn_fold_multi, dim3(n_chunks), dim3(256), 0, as_stream(stream), jobs, reinterpret_cast<const int2*>(chunks));
+  DASAC_CHECK_LAUNCH("bn_fold_multi");
   return DASAC_OK;
 }
 

@@ -167,6 +167,7 @@ class Engine:
                 self.last_use[s] = i
         self.last_use[plan.output] = len(plan.ops)
         self._tables, self._packs, self._folds = {}, {}, {}
+        self._refresh, self._fold_bufs = {}, {}
 
     def stale(self):
         """True when a module no longer holds the Parameter objects (or conv geometry) this engine captured:
@@ -250,10 +251,93 @@ class Engine:
             self._packs[slot] = ent
         return ent[1]
 
+    # ---------------------------------------------------------------- whole-network refresh of folds / packs
+    def _refresh_plan(self, device, transposed):
+        """Device job tables for `ops.refresh_network`: one fold job per frozen-BN conv, one pack job per (conv, layout) for
+        every single-branch, non-expanded conv.  Output buffers are persistent (their pointers sit in the tables)."""
+        key = (device.index, bool(transposed))
+        plan = self._refresh.get(key)
+        if plan is not None and plan["ptrs"] == self._refresh_ptrs():
+            return plan
+        lib = L.load()
+        fold_jobs, pack_jobs, fold_ops, pack_slots = [], [], [], []
+        for op in self.plan.ops:
+            if op.kind != "conv" or op.expanded is not None or len(op.convs) != 1:
+                continue
+            scale = None
+            if op.bn is not None:
+                ent = self._fold_bufs.get(id(op))
+                if ent is None:
+                    C = op.spec.cout
+                    ent = tuple(torch.empty(C, dtype=torch.float32, device=device) for _ in range(3))
+                    self._fold_bufs[id(op)] = ent
+                scale = ent[0]
+                cb = op.convs[0].bias if op.has_bias else None
+                fold_jobs.append((op.bn.weight, op.bn.bias, op.bn.running_mean, op.bn.running_var, cb, ent, op.bn.eps, op.spec.cout))
+                fold_ops.append(op)
+            for tr in ((False, True) if transposed else (False,)):
+                M = op.spec.cin if tr else op.spec.cout
+                K = op.spec.Kt if tr else op.spec.K
+                slot = (id(op), tr)
+                old = self._packs.get(slot)
+                shape = (lib.dasac_conv_kpad(K), lib.dasac_conv_mpad(M))
+                buf = old[1] if (old is not None and tuple(old[1].shape) == shape and not getattr(old[1], "dasac_x3", False)) else \
+                    torch.empty(shape, dtype=torch.float32, device=device)
+                buf.dasac_x3 = False
+                pack_jobs.append((op.convs[0].weight, scale, buf, op.spec.cout, op.spec.cin, op.spec.taps, shape[1], shape[0], int(tr),
+                                  ops.gemm_order(op.spec, tr)))
+                pack_slots.append((slot, op, buf, scale))
+        plan = {"ptrs": self._refresh_ptrs(), "fold_ops": fold_ops, "pack_slots": pack_slots,
+                "tables": ops.build_refresh_tables(fold_jobs, pack_jobs, device)}
+        self._refresh[key] = plan
+        return plan
+
+    def _refresh_ptrs(self):
+        out = []
+        for op in self.plan.ops:
+            if op.kind == "conv":
+                out += [p.data_ptr() for p in op.params()]
+                if op.bn is not None:
+                    out += [op.bn.running_mean.data_ptr(), op.bn.running_var.data_ptr()]
+        return tuple(out)
+
+    def refresh(self, device, transposed):
+        """After an optimiser / EMA step every folded BN vector and every packed weight operand of the network is stale at
+        once: rebuild them ALL in two launches (dasac_bn_fold_multi, dasac_conv_pack_multi) instead of one small launch per
+        layer and layout as they are first used (~310 launches per student step).  Only when the whole network is stale and
+        runs frozen-BN fp32 -- partial invalidations, batch-statistics BN and the split-bf16 operands keep the per-layer path."""
+        if ops.PRECISION != "fp32":
+            return
+        convs = [op for op in self.plan.ops if op.kind == "conv" and op.expanded is None and len(op.convs) == 1]
+        if len(convs) < 8 or any(op.bn is not None and op.bn.training for op in convs):
+            return
+        # stale = the cached key no longer matches the parameters' version counters
+        def pack_key(op, scale):
+            return (_ver(op.convs[0].weight),) + ((_ver(scale),) if scale is not None else ()) + (ops.PRECISION,)
+
+        def fold_key(op):
+            bn, cb = op.bn, (op.convs[0].bias if op.has_bias else None)
+            return (_ver(bn.weight), _ver(bn.bias), _ver(bn.running_mean), _ver(bn.running_var), None if cb is None else _ver(cb))
+        for op in convs:                                     # all-or-nothing: the first fresh layer ends the check
+            ent = self._packs.get((id(op), False))
+            sc = self._folds.get(id(op))
+            fresh_fold = op.bn is None or (sc is not None and sc[0] == fold_key(op))
+            if fresh_fold and ent is not None and ent[0] == pack_key(op, None if op.bn is None else sc[1][0]):
+                return
+        plan = self._refresh_plan(device, transposed)
+        ops.refresh_network(plan["tables"])
+        for op in plan["fold_ops"]:
+            ent = self._fold_bufs[id(op)]
+            ops.bump_versions([ent[0]])                      # the scale vector is part of the pack keys: it has new contents
+            self._folds[id(op)] = (fold_key(op), ent)
+        for slot, op, buf, scale in plan["pack_slots"]:
+            self._packs[slot] = (pack_key(op, scale), buf, scale)
+
     # ---------------------------------------------------------------- forward
     def forward(self, x, keep):
         """Runs the plan.  keep=True retains what backward needs; returns (output, saved)."""
         L.require_gpu(x)
+        self.refresh(x.device, transposed=keep)
         acts = {0: x}
         saved = {"acts": acts, "aux": {}}
         for i, op in enumerate(self.plan.ops):
@@ -532,6 +616,31 @@ def upsample_bilinear(logits, size):
     up = _Upsample.apply(logits, tuple(int(s) for s in size))
     up._dasac_low = (logits, up._version)      # valid only while `up` still holds U(logits): see _ce
     return up
+
+
+class _SplitBatch(torch.autograd.Function):
+    """x [B, ...] -> (x[:n], x[n:]) as two contiguous tensors sharing x's storage; backward writes the two gradients side by
+    side into one buffer (a missing one is zero)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = int(n), tuple(x.shape)
+        return x.narrow(0, 0, ctx.n), x.narrow(0, ctx.n, x.shape[0] - ctx.n)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ref = ga if ga is not None else gb
+        g = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        for part, grad in ((g.narrow(0, 0, ctx.n), ga), (g.narrow(0, ctx.n, ctx.shape[0] - ctx.n), gb)):
+            if grad is None:
+                part.zero_()
+            else:
+                part.copy_(grad)
+        return g, None
+
+
+def split_batch(x, n):
+    return _SplitBatch.apply(x, n)
 
 
 class _CELoss(torch.autograd.Function):

@@ -61,6 +61,9 @@ PROTOTYPES = {
     "dasac_tap_gather": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     "dasac_tap_scatter": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_conv_wgrad_finish_expanded": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "dasac_pack_chunk_elems": (_i, []),
+    "dasac_bn_fold_multi": (_i, [_p, _p, _i, _p]),
+    "dasac_conv_pack_multi": (_i, [_p, _p, _i, _p]),
     "dasac_label_pad_mask": (_i, [_p, _p, _l, _i, _i, _p]),
     "dasac_dropout_planes": (_i, [C.c_uint64, C.c_uint64, _f, _l, _p, _p]),
     "dasac_iou_counts": (_i, [_p, _p, _i, _i, _l, _i, _p, _p]),

@@ -479,6 +479,51 @@ def bn_fold(gamma, beta, mean, var, eps, conv_bias=None, want_invstd=True):
     return scale, shift, invstd
 
 
+def build_refresh_tables(fold_jobs, pack_jobs, device):
+    """Device tables for dasac_bn_fold_multi / dasac_conv_pack_multi (include/dasac_hip.h: dasac_fold_job, dasac_pack_job).
+    fold job: (gamma, beta, mean, var, conv_bias|None, (scale, shift, invstd), eps, C)
+    pack job: (weight, scale|None, out, Cout, Cin, taps, Mpad, Kpad, mode, order)"""
+    import numpy as np
+    lib = L.load()
+    fold_dt = np.dtype([("gamma", "<u8"), ("beta", "<u8"), ("mean", "<u8"), ("var", "<u8"), ("conv_bias", "<u8"), ("scale", "<u8"),
+                        ("shift", "<u8"), ("invstd", "<u8"), ("eps", "<f4"), ("C", "<i4")])
+    pack_dt = np.dtype([("w", "<u8"), ("scale", "<u8"), ("out", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("taps", "<i4"), ("Mpad", "<i4"),
+                        ("Kpad", "<i4"), ("mode", "<i4"), ("order", "<i4"), ("reserved", "<i4")])
+    assert fold_dt.itemsize == 72 and pack_dt.itemsize == 56
+    keep = []
+    fj = np.zeros(len(fold_jobs), dtype=fold_dt)
+    fchunks = []
+    for i, (g, b, m, v, cb, outs, eps, C) in enumerate(fold_jobs):
+        L.require_gpu(g, b, m, v, cb, *outs)
+        fj[i] = (g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), 0 if cb is None else cb.data_ptr(), outs[0].data_ptr(),
+                 outs[1].data_ptr(), outs[2].data_ptr(), float(eps), int(C))
+        fchunks += [(i, c) for c in range((C + 255) // 256)]
+        keep.append(outs)
+    pj = np.zeros(len(pack_jobs), dtype=pack_dt)
+    pchunks, chunk = [], lib.dasac_pack_chunk_elems()
+    for i, (w, sc, out, Cout, Cin, taps, Mpad, Kpad, mode, order) in enumerate(pack_jobs):
+        L.require_gpu(w, sc, out)
+        assert w.is_contiguous() and out.is_contiguous() and out.numel() == Kpad * Mpad
+        pj[i] = (w.data_ptr(), 0 if sc is None else sc.data_ptr(), out.data_ptr(), Cout, Cin, taps, Mpad, Kpad, mode, order, 0)
+        pchunks += [(i, c) for c in range((Kpad * Mpad + chunk - 1) // chunk)]
+        keep.append(out)
+    up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device) if a.size else None
+    upi = lambda l: torch.tensor(l, dtype=torch.int32).reshape(-1, 2).to(device) if l else None
+    return {"fold": up(fj), "fold_chunks": upi(fchunks), "n_fold_chunks": len(fchunks),
+            "pack": up(pj), "pack_chunks": upi(pchunks), "n_pack_chunks": len(pchunks), "keep": keep}
+
+
+def refresh_network(tables):
+    """All frozen-BN folds, then all packed weight operands of a network: two launches."""
+    lib = L.load()
+    if tables["n_fold_chunks"]:
+        L.check(lib.dasac_bn_fold_multi(tables["fold"].data_ptr(), tables["fold_chunks"].data_ptr(), tables["n_fold_chunks"],
+                                        L.stream_ptr()), "dasac_bn_fold_multi")
+    if tables["n_pack_chunks"]:
+        L.check(lib.dasac_conv_pack_multi(tables["pack"].data_ptr(), tables["pack_chunks"].data_ptr(), tables["n_pack_chunks"],
+                                          L.stream_ptr()), "dasac_conv_pack_multi")
+
+
 def bn_param_grads(dot, sum_dz, mean, invstd, scale, conv_bias, want_gamma=True, want_beta=True, want_bias=False, outs=(None, None, None)):
     lib = L.load()
     Cn = sum_dz.numel()

@@ -213,3 +213,10 @@ class OverlappedDataParallel(nn.Module):
         if self.broadcast_buffers:            # DDP syncs its buffers before EVERY forward (train, eval and no-grad alike)
             self._broadcast(self._synced_buffers)
         return self.module(*args, **kwargs)
+
+    def forward_fused(self, *args, **kwargs):
+        """`SAC.forward_fused` (both student passes of an iteration as one) under the same buffer synchronisation; the one
+        backward pass that follows reduces source + target gradients together."""
+        if self.broadcast_buffers:
+            self._broadcast(self._synced_buffers)
+        return self.module.forward_fused(*args, **kwargs)

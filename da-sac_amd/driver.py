@@ -106,7 +106,7 @@ def prep_batch(tensor, num_groups, group_size, rank=None, world=None, device=Non
 
 
 def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_teacher, lr_target, target_only=False,
-                        sum_grads_in_optimizer=True):
+                        sum_grads_in_optimizer=True, fuse_passes=False):
     """source fwd -> zero_grad -> source bwd (gradients kept) -> target fwd (teacher EMA first when asked)
     -> (LR_TARGET * self_ce) bwd -> one optimiser step.  Returns (source losses, target losses, net_outs)
     with the losses still on the device (no host sync here).  TRAIN.TARGET_ONLY skips the source pass altogether
@@ -118,7 +118,23 @@ def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_tea
     `.grad` holds the target-pass gradient only: anything that reads gradients before the step (clipping, norm logging)
     must use `optim.full_grads()` or pass sum_grads_in_optimizer=False (or another optimiser) for the reference's `.grad`
     contents.  Under data parallelism the update is mean_r(src_r) + mean_r(tgt_r) where the reference's DDP reduces
-    mean_r(mean(src) + tgt_r): equal in exact arithmetic, one rounding apart in fp32 (not bit-identical)."""
+    mean_r(mean(src) + tgt_r): equal in exact arithmetic, one rounding apart in fp32 (not bit-identical).
+
+    fuse_passes=True: the student runs ONCE over [source crops; target crops] and ONE backward pass differentiates
+    loss_ce + LR_TARGET * self_ce (`SAC.forward_fused`: same weights in both passes, frozen BN, teacher independent of the
+    student -- the same gradient sum, half the launches, one gradient all-reduce per iteration).  Needs the bare module or
+    `dasac_hip.parallel.OverlappedDataParallel`; silently runs the two-pass order where it does not apply (target_only, stock
+    DistributedDataParallel, batch-statistics BN)."""
+    core = net.module if hasattr(net, "module") else net
+    if fuse_passes and not target_only and hasattr(net, "forward_fused") and hasattr(core, "backbone") and core.backbone._bn_frozen():
+        images, masks = src_batch
+        frames1, frames_gt, frames2, affine, affine_inv = tgt_batch
+        losses_src, losses_tgt, outs = net.forward_fused(images, masks, frames1, frames_gt, frames2, affine, affine_inv,
+                                                         update_teacher=update_teacher, T=group_size)
+        optim.zero_grad()
+        (losses_src["loss_ce"].mean() + lr_target * losses_tgt["self_ce"].mean()).backward()
+        optim.step()
+        return losses_src, losses_tgt, outs
     losses_src = {}
     if not target_only:
         images, masks = src_batch

@@ -17,6 +17,7 @@ class BaseNet(nn.Module):
     # layer types whose weight/bias are optimised, and the normalisation types that can be frozen
     _trainable = (nn.Linear, nn.Conv2d, nn.ConvTranspose2d, nn.BatchNorm2d, nn.GroupNorm, nn.InstanceNorm2d, nn.SyncBatchNorm)
     _batchnorm = (nn.BatchNorm2d, nn.SyncBatchNorm, nn.GroupNorm)
+    _returns_logits = True          # net_outs carries the stride-8 "logits" next to "logits_up" (fcn.py:149 does not)
 
     def __init__(self):
         super().__init__()

@@ -9,6 +9,7 @@ from .deeplabv2 import _vgg16_features, plan_sequential, BatchNorm
 
 
 class VGG16_FCN8s(BaseNet):
+    _returns_logits = False         # fcn.py:149 returns only {"logits_up"}
 
     def __init__(self, num_classes, criterion=None, pretrained=None, use_bn=False, freeze_bn=False, drop_rate=0.1):
         super().__init__()

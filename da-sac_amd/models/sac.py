@@ -262,5 +262,53 @@ class SAC(SAC_Baseline):
             net_outs.update(diags)
         return losses, net_outs
 
+    def forward_fused(self, src_x, src_y, x, y, x2, affine, affine_inv, update_teacher=False, T=None):
+        """One training iteration's two student passes as ONE: `forward(src_x, src_y)` and
+        `forward(x, y, x2, affine, affine_inv, use_teacher=True, update_teacher=..., T=T)` (train.py:128,219-222), with
+        the student evaluated once on the concatenated batch [source crops; target crops].
+
+        Why this is the same computation: between the two passes of an iteration the reference takes no optimiser step
+        (train.py:132-138,231-233), so both see the same student weights; in SAC mode every BatchNorm is frozen
+        (models/__init__.py:29), so the samples of a batch do not interact; and the momentum teacher (EMA step, forward,
+        refinement, pseudo labels) never reads the student's activations.  Back-propagating loss_src + LR_TARGET * self_ce
+        through the one pass yields d loss_src + LR_TARGET * d self_ce -- what the two backward passes accumulate in .grad --
+        up to the summation order of the weight-gradient reductions.  What it buys: every student GEMM runs once over 16
+        crops instead of twice over 8 (half the launches, half the split-K slab traffic, one gradient all-reduce per
+        iteration instead of two).
+        Returns (source losses, target losses, net_outs) exactly as the two calls would (the target's ground-truth CE
+        `loss_ce` is still evaluated and still never back-propagated).  Needs equal source / target crop
+        sizes and frozen BN; not for the baseline (AdaBN) mode."""
+        assert self.backbone._bn_frozen(), "forward_fused: batch-statistics BN couples the samples of a pass"
+        assert tuple(src_x.shape[1:]) == tuple(x.shape[1:]), "forward_fused: source and target crops must have one size"
+        ignore_mask = ops.label_pad_mask(y, -1, 255)
+        losses_tgt = {}
+        if update_teacher:
+            print("Updating the teacher")
+            losses_tgt["teacher_diff"] = self._momentum_update(True)
+        self.slow_net.eval()
+        with torch.no_grad():
+            slow_logits, slow_logits_up = self.slow_net(x2)
+            probs_teacher, diags = self._refine(x2, slow_logits, T, affine, affine_inv, ignore_mask, pool=self.cfg.CONF_POOL_ON)
+            disc, fw = self._class_vectors.finish(self.cfg.THRESHOLD_BETA, self.cfg.FOCAL_P, self.cfg.CONF_DISCOUNT)
+            pseudo_labels, teacher_conf, _ = ops.pseudo_labels(probs_teacher, ignore_mask, self.cfg.RUN_CONF_UPPER,
+                                                               self.cfg.RUN_CONF_LOWER, disc)
+        n_src = src_x.shape[0]
+        logits = self.backbone._logits(torch.cat([src_x, x], 0))
+        logits_src, logits_tgt = E.split_batch(logits, n_src)
+        up_src = E.upsample_bilinear(logits_src, src_x.shape[-2:])
+        up_tgt = E.upsample_bilinear(logits_tgt, x.shape[-2:])
+        losses_src = {"loss_ce": E.ce_mean_all_pixels(up_src, src_y).view(1)}
+        losses_tgt["loss_ce"] = E.ce_mean_all_pixels(up_tgt, y).view(1)
+        conf = teacher_conf if self.cfg.LOSS == "focal_ce_conf" else None
+        losses_tgt["self_ce"] = E.focal_ce(up_tgt, pseudo_labels, fw, conf).view(1)
+        net_outs = {"logits_up": up_tgt}
+        if self.backbone._returns_logits:
+            net_outs["logits"] = logits_tgt
+        net_outs.update(teacher_init=slow_logits_up, teacher_refined=probs_teacher, teacher_conf=teacher_conf,
+                        teacher_labels=pseudo_labels, running_conf=self.running_conf)
+        losses_tgt["teacher_diff"] = self._momentum_update(False)
+        net_outs.update(diags)
+        return losses_src, losses_tgt, net_outs
+
     def parameter_groups(self, base_lr, wd):
         return self.backbone.parameter_groups(base_lr, wd)

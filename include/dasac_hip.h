@@ -274,6 +274,27 @@ int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const
                        const float* gamma, const double* sums, double count, const double* count_dev, int N, int C,
                        int64_t HW, float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);
 
+/* Whole-network refresh of the derived operands after an optimiser / EMA step -- what ~100 dasac_bn_fold and ~200
+ * dasac_conv_pack calls per step did, in two launches.  `jobs` are DEVICE arrays of the structs below, `chunks` device
+ * (job, chunk) int32 pairs: one chunk = 256 channels of a fold job / dasac_pack_chunk_elems() floats of a pack job's output
+ * (ceil(Kpad*Mpad / chunk) chunks per job; K and M padding are written as zeros).  Single-branch convolutions only
+ * (taps = kh*kw of the one branch); mode / order as in dasac_conv_pack, Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K). */
+typedef struct dasac_fold_job {
+  const float *gamma, *beta, *mean, *var, *conv_bias; /* conv_bias may be NULL */
+  float *scale, *shift, *invstd;
+  float eps;
+  int32_t C;
+} dasac_fold_job;
+typedef struct dasac_pack_job {
+  const float* w;     /* [Cout][Cin][taps] */
+  const float* scale; /* [Cout] folded into the operand, or NULL */
+  float* out;         /* [Kpad/4][Mpad][4] */
+  int32_t Cout, Cin, taps, Mpad, Kpad, mode, order, reserved;
+} dasac_pack_job;
+int dasac_pack_chunk_elems(void);
+int dasac_bn_fold_multi(const dasac_fold_job* jobs, const int32_t* chunks, int n_chunks, dasac_stream_t stream);
+int dasac_conv_pack_multi(const dasac_pack_job* jobs, const int32_t* chunks, int n_chunks, dasac_stream_t stream);
+
 /* models/sac.py:337-338  `ignore_mask = (y == -1); y[ignore_mask] = 255` in one pass: mask[i] = labels[i] == pad_label,
  * labels[i] = ignore_label there (in place, like the reference).  labels i64 [n], mask u8 [n]. */
 int dasac_label_pad_mask(int64_t* labels, uint8_t* mask, int64_t n, int pad_label, int ignore_label,

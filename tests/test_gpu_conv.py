@@ -172,3 +172,57 @@ def test_small_batch_stream_k_with_several_contributors(case):
     finally:
         ops.set_precision("fp32")
     assert rel_err(y3.double().cpu(), yr) < TOL
+
+
+def test_whole_network_refresh_equals_the_per_layer_folds_and_packs():
+    """Engine.refresh (dasac_bn_fold_multi + dasac_conv_pack_multi: every frozen-BN fold and every packed weight operand of
+    ResNet-101 in two launches) against the per-layer kernels it replaces -- bit for bit, forward and data-gradient layouts,
+    both K orders, K / M padding zeroed -- and that an optimiser-style in-place update makes the next forward refresh again."""
+    from types import SimpleNamespace as NS
+    import torch.nn as nn
+    import models
+    from dasac_hip import ops
+    from oracle import nets_ref as N
+    from oracle.step_ref import DEFAULT_CFG
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False))
+    net = models.get_model(cfg, 0, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    net.backbone.load_state_dict(N.resnet101_state(seed=2, randomize_bn=True, he_init=True), strict=True)
+    net.cuda().train()
+    bb = net.backbone
+    x = torch.randn(1, 3, 33, 49, device="cuda")
+    calls = []
+    real_pack, real_fold = ops.conv_pack, ops.bn_fold
+    ops.conv_pack = lambda *a, **k: (calls.append("pack"), real_pack(*a, **k))[1]
+    ops.bn_fold = lambda *a, **k: (calls.append("fold"), real_fold(*a, **k))[1]
+    try:
+        out = bb._logits(x)
+        out.sum().backward()
+        eng = bb._engine
+        assert not calls, calls[:4]                      # nothing went through the per-layer path
+        n = 0
+        for op in eng.plan.ops:
+            if op.kind != "conv" or op.expanded is not None:
+                continue
+            scale, shift, invstd = eng._folds[id(op)][1]
+            ws, wh, wi = real_fold(op.bn.weight.detach(), op.bn.bias.detach(), op.bn.running_mean, op.bn.running_var, op.bn.eps, None)
+            assert torch.equal(scale, ws) and torch.equal(shift, wh) and torch.equal(invstd, wi)
+            for tr in (False, True):
+                got = eng._packs[(id(op), tr)][1]
+                want = real_pack(op.spec, [op.convs[0].weight.detach()], tr, scale, order=ops.gemm_order(op.spec, tr))
+                assert got.shape == want.shape and torch.equal(got, want), (op.spec.cout, op.spec.cin, tr)
+                n += 1
+        assert n == 2 * 104
+        # in-place parameter update (what FusedSGD does): everything is stale again and is rebuilt by the next forward
+        with torch.no_grad():
+            for p in bb.parameters():
+                p.mul_(1.01)
+        before = eng._packs[(id(eng.plan.ops[0]), False)][1].clone()
+        bb._logits(x)
+        assert not calls and not torch.equal(before, eng._packs[(id(eng.plan.ops[0]), False)][1])
+        # one stale layer only: the per-layer path handles it
+        with torch.no_grad():
+            eng.plan.ops[5].convs[0].weight.mul_(0.5)
+        bb._logits(x)
+        assert calls == ["pack"]
+    finally:
+        ops.conv_pack, ops.bn_fold = real_pack, real_fold

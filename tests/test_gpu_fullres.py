@@ -13,10 +13,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cfg3_resolution_sample_matches_the_oracle():
+_SAMPLE = {}
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_cfg3_resolution_sample_matches_the_oracle(fuse):
+    """fuse: the student's source and target passes as one (what bench.py times) or one after the other (train.py:266-298)."""
     sys.path.insert(0, ROOT)
     import bench
-    (_, cores), cmp_ = bench.parity_fullres(769)
+    if "s" not in _SAMPLE:
+        _SAMPLE["s"] = bench.cpu_sample(769)                  # the oracle's 14 s once for both schedules
+    (_, cores), cmp_ = bench.parity_fullres(769, sample=_SAMPLE["s"], fuse=fuse)
     print("parity_fullres:", cmp_, "cores", cores)
     assert cmp_["labelled_frac"] > 0.05                       # the thresholds fire: the label comparison is not vacuous
     assert cmp_["loss_ce_rel"] <= 1e-4

@@ -378,3 +378,66 @@ def test_three_sac_iterations_with_teacher_updates_vs_oracle():
     assert seen[0] == 0.0 and seen[1] > 0.0 and seen[2] > 0.0
     w, w_ref = net.slow_net.state_dict()["model.layer4.2.conv3.weight"].cpu(), ref.teacher["model.layer4.2.conv3.weight"].detach()
     assert rel_err(w, w_ref) < 1e-3
+
+
+@pytest.mark.parametrize("wrapped", [False, True])
+def test_fused_iteration_equals_the_two_pass_iteration_and_the_oracle(wrapped):
+    """driver.sac_train_iteration(fuse_passes=True) -- the student evaluated ONCE on [source; target] crops, one backward pass
+    over loss_ce + LR_TARGET * self_ce (SAC.forward_fused) -- against the reference's two passes (train.py:266-298) on the same
+    module, and against the CPU oracle's two passes: same losses, same label maps, same parameters after the step (the
+    weight-gradient reductions run over 4 crops at once instead of 2 + 2: summation order only)."""
+    import models
+    import driver
+    from oracle import step_ref as S
+    from dasac_hip.parallel import OverlappedDataParallel
+    kw = dict(NET_MOMENTUM=0.5, LR=2e-3)
+    cfg = model_cfg(**kw)
+    sd = N.resnet101_state(seed=4, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2)
+    ref = S.SacOracle(sd, cfg=dict(S.DEFAULT_CFG, **kw))
+    ref_opt = S.SgdOracle(ref)
+    nets, opts, steps = [], [], []
+    for fused in (False, True):
+        net = models.get_model(cfg, 0, num_classes=19, criterion=CRIT)
+        net.backbone.load_state_dict(sd, strict=True)
+        net.cuda().train()
+        nets.append(net)
+        opts.append(driver.make_optimizer(net, cfg))
+        steps.append(OverlappedDataParallel(net, device_ids=[0]) if (wrapped and fused) else net)
+    to = lambda ts: tuple(t.cuda() for t in ts)
+    for it in range(3):
+        src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cpu", seed=40 + it)
+        ls_r, lt_r, outs_r = S.sac_train_iteration(ref, ref_opt, src, tuple(t.clone() for t in tgt), 2, it != 1)
+        got = [driver.sac_train_iteration(steps[f], opts[f], to(src), to(tgt), 2, it != 1, cfg.LR_TARGET, fuse_passes=bool(f))
+               for f in (0, 1)]
+        (ls0, lt0, o0), (ls1, lt1, o1) = got
+        assert set(lt1) == set(lt0) == {"loss_ce", "self_ce", "teacher_diff"} and set(o1) == set(o0)
+        for key in o1:
+            assert o1[key].is_contiguous() and o1[key].shape == o0[key].shape and o1[key].dtype == o0[key].dtype, key
+        # the teacher side does not depend on how the student is batched: bit-equal on equal weights (iteration 0)
+        if it == 0:
+            assert torch.equal(o0["teacher_labels"], o1["teacher_labels"]) and torch.equal(o0["teacher_refined"], o1["teacher_refined"])
+            assert float(ls0["loss_ce"]) == pytest.approx(float(ls1["loss_ce"]), rel=1e-6)
+            assert float(lt0["self_ce"]) == pytest.approx(float(lt1["self_ce"]), rel=1e-6)
+            assert float(lt0["loss_ce"]) == pytest.approx(float(lt1["loss_ce"]), rel=1e-6)
+            # one optimiser step from equal weights: the two schedules differ by the summation order of the weight-gradient
+            # reductions only (4 crops at once instead of 2 + 2) -- and both sit on the oracle's parameters
+            sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+            for k in sd0:
+                if sd0[k].is_floating_point():
+                    assert rel_err(sd1[k], sd0[k]) < 2e-6, k
+            for k in ("model.conv1.weight", "model.layer3.7.conv2.weight", "model.layer4.2.bn3.weight", "model.layer5.conv2d_list.2.weight"):
+                assert rel_err(nets[1].backbone.state_dict()[k], ref.student[k].detach()) < 1e-5, k
+        assert float(ls1["loss_ce"]) == pytest.approx(ls_r["loss_ce"], rel=2e-3), it
+        assert float(lt1["loss_ce"]) == pytest.approx(lt_r["loss_ce"], rel=2e-3), it
+        assert float(lt1["teacher_diff"]) == pytest.approx(lt_r["teacher_diff"], rel=2e-3, abs=1e-6), it
+        assert float(lt1["self_ce"]) == pytest.approx(lt_r["self_ce"], rel=2e-2, abs=1e-5), it
+        assert float((o1["teacher_labels"].cpu() != outs_r["teacher_labels"]).float().mean()) < 5e-3, it
+    # three free-running optimiser steps at 8x the reference LR later the two schedules have drifted apart by what borderline
+    # ReLUs / pseudo-labels do to any two fp32 summation orders (the oracle comparison of the existing three-iteration test
+    # drifts the same way): a loose bound here, the tight one was taken right after the first step above
+    sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+    for k in sd0:
+        if sd0[k].is_floating_point():
+            assert rel_err(sd1[k], sd0[k]) < 2e-2, k
+    for k in ("model.conv1.weight", "model.layer3.7.conv2.weight", "model.layer4.2.bn3.weight", "model.layer5.conv2d_list.2.weight"):
+        assert rel_err(nets[1].backbone.state_dict()[k], ref.student[k].detach()) < 2e-2, k
