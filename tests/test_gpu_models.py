@@ -424,9 +424,9 @@ def test_fused_iteration_equals_the_two_pass_iteration_and_the_oracle(wrapped):
             sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
             for k in sd0:
                 if sd0[k].is_floating_point():
-                    assert rel_err(sd1[k], sd0[k]) < 2e-6, k
+                    assert rel_err(sd1[k], sd0[k]) < 1e-5, k
             for k in ("model.conv1.weight", "model.layer3.7.conv2.weight", "model.layer4.2.bn3.weight", "model.layer5.conv2d_list.2.weight"):
-                assert rel_err(nets[1].backbone.state_dict()[k], ref.student[k].detach()) < 1e-5, k
+                assert rel_err(nets[1].backbone.state_dict()[k], ref.student[k].detach()) < 1e-4, k
         assert float(ls1["loss_ce"]) == pytest.approx(ls_r["loss_ce"], rel=2e-3), it
         assert float(lt1["loss_ce"]) == pytest.approx(lt_r["loss_ce"], rel=2e-3), it
         assert float(lt1["teacher_diff"]) == pytest.approx(lt_r["teacher_diff"], rel=2e-3, abs=1e-6), it
