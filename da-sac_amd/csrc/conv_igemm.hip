@@ -51,6 +51,14 @@ struct Epilogue {
   const float* res;     // same layout as out, or null  (added before ReLU)
   const float* mask;    // same layout as out, or null  (out = mask>0 ? out : 0, ReLU backward)
   int relu;
+  // ReLU pattern as ONE BIT per element instead of a whole fp32 activation read back only to test `> 0`:
+  //   bits[m][pix >> 5] bit (pix & 31), pix = flattened (n, oh, ow) index of the GEMM's pixel axis, w32 = ceil(Npix / 32) words
+  //   per row.  A 32-pixel group of a tile is 32-aligned (tiles start at multiples of 128), so every word belongs to exactly one
+  //   wave: the producer (forward conv with ReLU) writes obits from wave ballots, the consumer (the data-gradient GEMM whose
+  //   output has the producer's shape) reads mbits -- 1/32 of the fp32 mask's bytes.
+  const unsigned* mbits;   // consumer: out = bit ? out : 0    (exclusive with `mask`)
+  unsigned* obits;         // producer: bit = out > 0 (after ReLU); ostride must be 1
+  int w32;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -84,6 +92,29 @@ __device__ __forceinline__ f32x4 buf_f32x4_sc1(__amdgpu_buffer_rsrc_t r, unsigne
 __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+
+// v_writelane_b32 with a compile-time lane (this clang has no writelane builtin; the lane select must be an inline constant or
+// M0, and M0 is reserved).  put_mask_rows: the two 32-bit halves of a wave ballot over accumulator register `rg` are the mask
+// words of rows (rg&3) + 8*(rg>>2) (lanes 0-31) and 4 below (lanes 32-63) of a 32x32 MFMA tile: lane r of `acc` collects row r.
+template <int LANE>
+__device__ __forceinline__ int writelane_c(int val, int old) {
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(LANE));
+  return old;
+}
+__device__ __forceinline__ int put_mask_rows(int rg, unsigned long long ballot, int acc) {
+  const int lo = (int)(unsigned)ballot, hi = (int)(unsigned)(ballot >> 32);
+  switch (rg) {      // rg is the index of a fully unrolled loop: the switch folds to one case
+#define DASAC_ROW_(RG)                                               \
+  case RG:                                                           \
+    acc = writelane_c<(RG & 3) + 8 * (RG >> 2)>(lo, acc);            \
+    acc = writelane_c<(RG & 3) + 8 * (RG >> 2) + 4>(hi, acc);        \
+    break;
+    DASAC_ROW_(0) DASAC_ROW_(1) DASAC_ROW_(2) DASAC_ROW_(3) DASAC_ROW_(4) DASAC_ROW_(5) DASAC_ROW_(6) DASAC_ROW_(7)
+    DASAC_ROW_(8) DASAC_ROW_(9) DASAC_ROW_(10) DASAC_ROW_(11) DASAC_ROW_(12) DASAC_ROW_(13) DASAC_ROW_(14) DASAC_ROW_(15)
+#undef DASAC_ROW_
+  }
+  return acc;
 }
 
 // Split-bf16 ("bf16x3") operands: x = head + tail with head = bf16(x) (round to nearest even) and
@@ -124,7 +155,10 @@ __device__ __forceinline__ void split_bf16(f32x4 v0, f32x4 v1, f32x4& heads, f32
 // workers is required -- and raises a flag.  The hand-off is placement independent (the per-XCD L2s are not coherent):
 // deposits are written with agent-scope (sc1, write-through) 16-byte stores and read with sc1 loads, the flag is an
 // agent-scope atomic that its single consumer resets (self-cleaning: no memset between launches).
-template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3>
+// BITS: 0 = fp32 epilogue operands only; 1 = the ReLU epilogue also records its pattern as bits (Epilogue::obits);
+//       2 = the epilogue masks with a recorded bit pattern (Epilogue::mbits).  Separate instantiations, so that the plain
+//       kernels carry none of the extra scalar state.
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3, int BITS = 0>
 __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
@@ -161,7 +195,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
   const int OutHW = g.OutH * g.OutW;
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(Out, g.out_bytes);
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(ep.res ? ep.res : Out, g.out_bytes);
-  const __amdgpu_buffer_rsrc_t rmsk = make_rsrc(ep.mask ? ep.mask : Out, g.out_bytes);
+  const __amdgpu_buffer_rsrc_t rmsk = BITS == 2 ? make_rsrc(ep.mbits, g.M * ep.w32 * 4) : make_rsrc(ep.mask ? ep.mask : Out, g.out_bytes);
   const __amdgpu_buffer_rsrc_t rsh = make_rsrc(ep.shift ? ep.shift : Out, ep.shift ? g.M * 4 : 0);
   const bool ragged = (g.M & 7) != 0;
   const __amdgpu_buffer_rsrc_t rpart = make_rsrc(STREAMK ? (const void*)partial : (const void*)Out,
@@ -428,10 +462,13 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
         const int oh = r / g.OW, ow = r - oh * g.OW;
         vo = (unsigned)(n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHW) * 4u;
       }
+      const int wcol = (n0 + wn * WN + j * 32) >> 5;          // this wave's 32-pixel group = one word column of the bit masks
+      const unsigned vmb = (unsigned)(4 * lh * ep.w32 + wcol) * 4u;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int mrow = m0 + wm * WM + i * 32;             // + (rg&3) + 8*(rg>>2) (+4*lh in the lane offset)
         if (mrow >= g.M) continue;                           // whole 32-row group beyond M (uniform)
+        int bitrows = 0;                                     // producer: lane r collects the mask word of row mrow + r
         // 8 rows at a time: one batch of loads (shift, residual, mask), then the arithmetic and the stores;
         // the compiler barrier keeps the batches from being merged (register pressure -> occupancy).
 #pragma unroll
@@ -446,6 +483,8 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
             const bool rowok = ragged ? (mr + 4 * lh < g.M) : (mr < g.M);
             vrow[u] = rowok ? vo : kPoison;
             sh[u] = ep.shift ? buf_f32(rsh, rowok ? (unsigned)(4 * lh) * 4u : kPoison, mr * 4) : 0.f;
+            if constexpr (BITS == 2)      // one word per (row, 32-pixel group): the 32 lanes of a half-wave read the same 4 bytes
+              mk[u] = buf_f32(rmsk, rowok ? vmb : kPoison, mr * ep.w32 * 4);
           }
           if (ep.res) {
 #pragma unroll
@@ -454,7 +493,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
               rs[u] = buf_f32(rres, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
             }
           }
-          if (ep.mask) {
+          if (BITS != 2 && ep.mask) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const int rg = half * 8 + u;
@@ -467,10 +506,16 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
             float v = acc[i][j][rg] + sh[u];
             if (ep.res) v = v + rs[u];
             if (ep.relu) v = fmaxf(v, 0.f);
-            if (ep.mask) v = mk[u] > 0.f ? v : 0.f;
+            if (BITS != 2 && ep.mask) v = mk[u] > 0.f ? v : 0.f;
+            if constexpr (BITS == 2) v = ((__float_as_uint(mk[u]) >> li) & 1u) ? v : 0.f;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4, 0);
+            if constexpr (BITS == 1)      // lanes 0-31 hold row (rg&3) + 8*(rg>>2), lanes 32-63 the row 4 below it: two words per ballot
+              bitrows = put_mask_rows(rg, __builtin_amdgcn_ballot_w64(v > 0.f), bitrows);
           }
           asm volatile("" ::: "memory");
+        }
+        if constexpr (BITS == 1) {
+          if (lane < 32 && mrow + lane < g.M) ep.obits[(size_t)(mrow + lane) * ep.w32 + wcol] = (unsigned)bitrows;
         }
       }
     }
@@ -983,7 +1028,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P,
     for (int u = 0; u < kWrTaps; ++u) acc[u] = 0.f;
     if (ci < Cin) {
       const float* p0 = P + (size_t)co * Kpad + (size_t)(tap0 + tb) * Cin + ci;
-      for (int s2 = q; s2 < splits; s2 += 4) {
+#pragma unroll 4
+      for (int s2 = q; s2 < splits; s2 += 4) {         // unrolled: the loads of four splits are issued before the first add
         const float* ps = p0 + (size_t)s2 * slab;
 #pragma unroll
         for (int u = 0; u < kWrTaps; ++u)
@@ -1071,7 +1117,7 @@ static bool want_streamk(int tiles, int k_steps) {
 }
 
 // `n_tiles` pixel tiles starting at g.n_tile0; schedule 0 = pick (want_streamk), 1 = one block per tile, 2 = stream-K
-template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool X3 = false>
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool X3 = false, int BITS = 0>
 static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
                        const Epilogue& ep, int n_tiles, int schedule, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
@@ -1083,13 +1129,13 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
     if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
     float* partial = reinterpret_cast<float*>(workspace);
     int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
-    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g, ep,
-                       m_tiles, n_tiles, partial, flags);
+    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
+                       ep, m_tiles, n_tiles, partial, flags);
     return DASAC_OK;
   }
   const int n_tiles_pad = (n_tiles + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false, X3>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp, tab,
-                     Out, g, ep, m_tiles, n_tiles, nullptr, nullptr);
+  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false, X3, BITS>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp,
+                     tab, Out, g, ep, m_tiles, n_tiles, nullptr, nullptr);
   return DASAC_OK;
 }
 
@@ -1190,18 +1236,28 @@ extern "C" size_t dasac_conv_gemm_workspace(void) {
   return (size_t)kSkWorkers * 128 * 128 * sizeof(float) + (size_t)(kSkWorkers + 1) * sizeof(int);
 }
 
+extern "C" size_t dasac_relu_bits_words(int M, int64_t Npix) { return (size_t)M * (size_t)((Npix + 31) / 32); }
+// 1 when dasac_conv_gemm (fp32) can record / consume bit masks for an output of M channels over a gathered tensor of Cx channels
+extern "C" int dasac_conv_gemm_bits_ok(int M, int Cx) { return (pick_bm(dasac_conv_mpad(M)) == 128 && Cx % kBK == 0) ? 1 : 0; }
+
 static int conv_gemm_impl(bool x3, const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx, int H,
                           int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride, const float* shift,
-                          const float* res, const float* mask, int relu, int pix_begin, int pix_count, int schedule,
-                          void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+                          const float* res, const float* mask, const uint32_t* mask_bits, uint32_t* relu_bits_out, int relu,
+                          int pix_begin, int pix_count, int schedule, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
   DASAC_REQUIRE(x && packed && table && out, "conv_gemm: null pointer");
+  DASAC_REQUIRE(!(mask && mask_bits), "conv_gemm: give the ReLU pattern as fp32 mask OR as bit mask");
+  DASAC_REQUIRE(!(mask_bits || relu_bits_out) || (ostride == 1 && OutH == OH && OutW == OW),
+                "conv_gemm: bit masks index the GEMM's own pixel axis (ostride must be 1)");
+  DASAC_REQUIRE(!relu_bits_out || relu, "conv_gemm: relu_bits_out records the pattern of a ReLU epilogue");
+  DASAC_REQUIRE(!(x3 && (mask_bits || relu_bits_out)), "conv_gemm_x3: bit masks are implemented for the fp32 kernel only");
   GemmGeom g;
   const int Mpad = dasac_conv_mpad(M), Kloop = (K + kBK - 1) / kBK * kBK;   // table/pack are padded to 128 >= Kloop
   int rc = fill_geom(g, Nb, Cx, H, W, OH, OW, stride, M, Mpad, Kloop, OutH, OutW, ostride);
   if (rc) return rc;
   DASAC_REQUIRE((int64_t)dasac_conv_kpad(K) * Mpad * 4 < (1ll << 31), "conv: packed weights exceed 2 GiB");
   g.w_bytes = dasac_conv_kpad(K) * Mpad * 4;
-  Epilogue ep{shift, res, mask, relu};
+  Epilogue ep{shift, res, mask, relu, mask_bits, relu_bits_out, (g.Npix + 31) / 32};
+  DASAC_REQUIRE((int64_t)M * ep.w32 * 4 < (1ll << 31), "conv_gemm: bit mask exceeds the 2 GiB buffer-descriptor window");
   const int4* tab = reinterpret_cast<const int4*>(table);
   hipStream_t s = as_stream(stream);
   const bool fast = Cx % kBK == 0;      // a K-step never straddles two taps
@@ -1227,6 +1283,15 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
     DASAC_CHECK_LAUNCH("conv_gemm_x3");
     return DASAC_OK;
   }
+  if (mask_bits || relu_bits_out) {
+    DASAC_REQUIRE(dasac_conv_gemm_bits_ok(M, Cx) && !(mask_bits && relu_bits_out),
+                  "conv_gemm: bit masks need the 128-row fp32 tile with Cx %% 16 == 0 (dasac_conv_gemm_bits_ok), one direction per call");
+    rc = relu_bits_out ? launch_gemm<128, 128, 2, kBK, true, false, 1>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
+                       : launch_gemm<128, 128, 2, kBK, true, false, 2>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
+    if (rc) return rc;
+    DASAC_CHECK_LAUNCH("conv_gemm");
+    return DASAC_OK;
+  }
   switch (bm) {
     case 128:
       rc = fast ? launch_gemm<128, 128, 2, kBK, true>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
@@ -1248,20 +1313,21 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
 
 extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx,
                                int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
-                               const float* shift, const float* res, const float* mask, int relu,
-                               int pix_begin, int pix_count, int schedule,
+                               const float* shift, const float* res, const float* mask, const uint32_t* mask_bits,
+                               uint32_t* relu_bits_out, int relu, int pix_begin, int pix_count, int schedule,
                                void* workspace, size_t ws_bytes, dasac_stream_t stream) {
   return conv_gemm_impl(false, x, packed, table, out, Nb, Cx, H, W, OH, OW, stride, M, K, OutH, OutW, ostride, shift, res, mask,
-                        relu, pix_begin, pix_count, schedule, workspace, ws_bytes, stream);
+                        mask_bits, relu_bits_out, relu, pix_begin, pix_count, schedule, workspace, ws_bytes, stream);
 }
 
 extern "C" int dasac_conv_gemm_x3(const float* x, const void* packed_x3, const int32_t* table, float* out, int Nb, int Cx,
                                   int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
-                                  const float* shift, const float* res, const float* mask, int relu,
-                                  int pix_begin, int pix_count, int schedule,
+                                  const float* shift, const float* res, const float* mask, const uint32_t* mask_bits,
+                                  uint32_t* relu_bits_out, int relu, int pix_begin, int pix_count, int schedule,
                                   void* workspace, size_t ws_bytes, dasac_stream_t stream) {
   return conv_gemm_impl(true, x, reinterpret_cast<const float*>(packed_x3), table, out, Nb, Cx, H, W, OH, OW, stride, M, K, OutH,
-                        OutW, ostride, shift, res, mask, relu, pix_begin, pix_count, schedule, workspace, ws_bytes, stream);
+                        OutW, ostride, shift, res, mask, mask_bits, relu_bits_out, relu, pix_begin, pix_count, schedule, workspace,
+                        ws_bytes, stream);
 }
 
 extern "C" int dasac_conv_pack_x3(const float* packed, int M, int K, void* packed_x3, dasac_stream_t stream) {

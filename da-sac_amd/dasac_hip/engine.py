@@ -168,6 +168,15 @@ class Engine:
         self.last_use[plan.output] = len(plan.ops)
         self._tables, self._packs, self._folds = {}, {}, {}
         self._refresh, self._fold_bufs = {}, {}
+        # A ReLU conv's pattern is recorded as bits when the backward pass will apply it in a stride-1 data-gradient epilogue:
+        # the mask is applied by the consumer that finishes LAST in backward order = the slot's FIRST consumer in plan order.
+        self._bits_wanted = [False] * plan.n_slots
+        first_consumer = {}
+        for op in plan.ops:
+            for s_ in self._inputs(op):
+                first_consumer.setdefault(s_, (op, s_ == op.src))
+        for slot, (op, is_src) in first_consumer.items():
+            self._bits_wanted[slot] = bool(is_src and op.kind == "conv" and op.spec.stride == 1 and slot != 0)
 
     def stale(self):
         """True when a module no longer holds the Parameter objects (or conv geometry) this engine captured:
@@ -339,7 +348,7 @@ class Engine:
         L.require_gpu(x)
         self.refresh(x.device, transposed=keep)
         acts = {0: x}
-        saved = {"acts": acts, "aux": {}}
+        saved = {"acts": acts, "aux": {}, "bits": {}}
         for i, op in enumerate(self.plan.ops):
             xin = acts[op.src]
             if op.kind == "conv":
@@ -365,9 +374,13 @@ class Engine:
                         saved["aux"][i] = (z, stats)
                 else:
                     scale, shift, _ = self.fold(op)
+                    bits = None
+                    if keep and op.relu and self._bits_wanted[op.dst] and ops.bits_ok(op.spec.cout, op.spec.cin):
+                        bits = ops.ReluBits(Nb, op.spec.cout, OH, OW, xin.device)
+                        saved["bits"][op.dst] = bits
                     ops.conv_gemm(xin, self.packed(op, False, scale), self.table(op, H, W, False, xin.device), out, (OH, OW),
                                   op.spec.stride, op.spec.cout, op.spec.K, 1, shift,
-                                  None if op.res is None else acts[op.res], None, op.relu)
+                                  None if op.res is None else acts[op.res], None, op.relu, bits_out=bits)
             elif op.kind == "pool":
                 out, arg = ops.maxpool_fwd(xin, op.k, op.s, op.p, op.ceil)
                 if keep:
@@ -409,7 +422,14 @@ class Engine:
         `sink.done(indices)` is called after each op, in backward order, so that a bucket's all-reduce can start while
         the layers below it are still being differentiated (DistributedDataParallel's overlap, train.py:104,133,232)."""
         acts, aux = saved["acts"], saved["aux"]
+        bits = saved.get("bits", {})
         grads = [None] * len(self.params)
+
+        def relu_pattern(slot, M, Cx):
+            """What the data-gradient epilogue (output M channels, gathering Cx) masks with: the producer's bit mask when the
+            forward recorded one and this GEMM has the bit-mask variant, else the producer's fp32 output."""
+            b = bits.get(slot)
+            return b if (b is not None and ops.bits_ok(M, Cx)) else acts[slot]
 
         def dest(j):
             return sink.alloc(j) if (sink is not None and need[j]) else None
@@ -471,7 +491,7 @@ class Engine:
                     if op.src != 0:
                         pending[op.src] -= 1
                         last = pending[op.src] == 0
-                        mask = acts[op.src] if (last and relu_producer(op.src)) else None
+                        mask = relu_pattern(op.src, spec.cin, ex.E) if (last and relu_producer(op.src)) else None
                         g[op.src] = ex.dgrad(d, self.packed_e(op, True), self.table_e(op, H, W, True, dz.device), (H, W),
                                              res=g.get(op.src), mask=mask)
                     acts.pop(op.dst, None)
@@ -537,7 +557,8 @@ class Engine:
                 if op.src != 0:
                     pending[op.src] -= 1
                     last = pending[op.src] == 0
-                    mask = acts[op.src] if (last and relu_producer(op.src)) else None
+                    mask = (relu_pattern(op.src, spec.cin, spec.cout) if spec.stride == 1 else acts[op.src]) \
+                        if (last and relu_producer(op.src)) else None
                     OH, OW = dz.shape[2:]
                     g[op.src] = ops.conv_dgrad(spec, dz, None, (H, W), scale=scale, res=g.get(op.src), mask=mask,
                                                table=self.table(op, OH, OW, True, dz.device),

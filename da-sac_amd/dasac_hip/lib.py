@@ -20,8 +20,10 @@ PROTOTYPES = {
     "dasac_conv_kpad": (_i, [_i]),
     "dasac_conv_table": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_conv_pack": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "dasac_conv_gemm": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
-    "dasac_conv_gemm_x3": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "dasac_relu_bits_words": (_sz, [_i, _l]),
+    "dasac_conv_gemm_bits_ok": (_i, [_i, _i]),
+    "dasac_conv_gemm": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "dasac_conv_gemm_x3": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "dasac_conv_pack_x3": (_i, [_p, _i, _i, _p, _p]),
     "dasac_conv_gemm_workspace": (_sz, []),
     "dasac_conv_gemm_schedule": (_i, [_i, _i, _i, _i, _i]),

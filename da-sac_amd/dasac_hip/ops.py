@@ -169,27 +169,52 @@ def conv_pack(spec, weights, transposed, scale=None, out=None, order=0):
     return _finish_pack(out, M, K)
 
 
-def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=None, res=None, mask=None, relu=False):
-    """out[n,m,oh*os,ow*os] = epilogue(sum_k packed[k][m] * gather(x)); see dasac_conv_gemm."""
+RELU_BITS = os.environ.get("DASAC_RELU_BITS", "1") != "0"      # ReLU patterns as bit masks (1/32 of the bytes) between fwd and dgrad
+
+
+def bits_ok(M, Cx):
+    """True when the fp32 conv GEMM for an output of M channels over Cx gathered channels has a bit-mask variant."""
+    return RELU_BITS and PRECISION == "fp32" and bool(L.load().dasac_conv_gemm_bits_ok(int(M), int(Cx)))
+
+
+class ReluBits:
+    """ReLU pattern of one activation tensor [Nb, M, OH, OW] as bits (include/dasac_hip.h: dasac_conv_gemm relu_bits_out)."""
+
+    def __init__(self, Nb, M, OH, OW, device):
+        self.shape = (Nb, M, OH, OW)
+        self.words = torch.empty(L.load().dasac_relu_bits_words(M, Nb * OH * OW), dtype=torch.int32, device=device)
+
+
+def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=None, res=None, mask=None, relu=False, bits_out=None):
+    """out[n,m,oh*os,ow*os] = epilogue(sum_k packed[k][m] * gather(x)); see dasac_conv_gemm.
+    mask: fp32 activation (zero where <= 0) or a ReluBits of the output's shape; bits_out: ReluBits to fill (relu only)."""
     lib = L.load()
     L.require_gpu(x, packed, table, out)
     Nb, Cx, H, W = x.shape
     OH, OW = grid_hw
     assert out.shape[0] == Nb and out.shape[1] == M and x.is_contiguous() and out.is_contiguous()
+    mask_bits = None
+    if isinstance(mask, ReluBits):
+        assert mask.shape == tuple(out.shape) and ostride == 1
+        mask_bits, mask = mask.words, None
+    if bits_out is not None:
+        assert relu and ostride == 1 and bits_out.shape == tuple(out.shape)
     for t_ in (res, mask):
         assert t_ is None or (t_.shape == out.shape and t_.is_contiguous())
     ws = L.workspace(lib.dasac_conv_gemm_workspace(), x.device, owner="conv_gemm")
     fn = lib.dasac_conv_gemm_x3 if getattr(packed, "dasac_x3", False) else lib.dasac_conv_gemm
-    tag = (M, K, Nb * OH * OW, stride, ostride, res is not None, mask is not None)
+    tag = (M, K, Nb * OH * OW, stride, ostride, res is not None, mask is not None or mask_bits is not None)
 
     def launch(span, pix_begin, pix_count, schedule):
         n = pix_count if pix_count else Nb * OH * OW - pix_begin
         frac = n / float(Nb * OH * OW)
-        nbytes = 4.0 * (x.numel() * frac + packed.numel() + n * M * (1 + (res is not None) + (mask is not None)))
+        nbytes = 4.0 * (x.numel() * frac + packed.numel() + n * M * (1 + (res is not None) + (mask is not None)
+                                                                     + ((mask_bits is not None) + (bits_out is not None)) / 32.0))
         with PROFILE.span(span, 2.0 * n * M * K, tag, nbytes):
             L.check(fn(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
                        stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
-                       L.ptr(mask), int(relu), pix_begin, pix_count, schedule, L.ptr(ws), 0 if ws is None else ws.numel(),
+                       L.ptr(mask), L.ptr(mask_bits), 0 if bits_out is None else bits_out.words.data_ptr(), int(relu),
+                       pix_begin, pix_count, schedule, L.ptr(ws), 0 if ws is None else ws.numel(),
                        L.stream_ptr()), "dasac_conv_gemm")
 
     lead = lib.dasac_conv_gemm_plan(Nb, OH, OW, M, K)
@@ -231,6 +256,7 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
         dx.zero_()
     else:
         dx = res
+    assert not isinstance(mask, ReluBits), "strided data gradient: the pattern is applied by relu_mask on the fp32 activation"
     conv_gemm(dz, packed, table, dx, (OH, OW), 1, spec.cin, spec.Kt, spec.stride, None,
               dx if res is not None else None, None, False)
     return relu_mask(dx, mask) if mask is not None else dx

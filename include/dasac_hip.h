@@ -72,7 +72,13 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *                    against scale*W, so the epilogue only adds the shift.
  *                    Call once per branch (tap0 = first tap of the branch, total_taps = all).
  * dasac_conv_gemm    out[n,m,oh*os,ow*os] = epi( sum_k packed[k][m] * x[n, c, oh*stride+dh, ow*stride+dw] )
- *                    epi: v + shift[m] (+res) (ReLU) (zeroed where mask <= 0).  The launch covers the
+ *                    epi: v + shift[m] (+res) (ReLU) (zeroed where mask <= 0 / where its mask bit is clear).
+ *                    ReLU patterns may travel as ONE BIT per element instead of the fp32 activation:
+ *                    `relu_bits_out` (with relu = 1) receives bit (pix & 31) of word [m][pix >> 5] = (out > 0), pix =
+ *                    flattened (n, oh, ow) index, dasac_relu_bits_words(M, Nb*OH*OW) uint32 words; `mask_bits`
+ *                    consumes such a pattern in the data-gradient GEMM whose output has the producer's shape
+ *                    (1/32 of the mask bytes; exclusive with `mask`; both need ostride = 1 and
+ *                    dasac_conv_gemm_bits_ok(M, Cx): the 128-row fp32 tile, Cx % 16 == 0).  The launch covers the
  *                    output pixels [pix_begin, pix_begin + pix_count) of the flattened (n, oh, ow) grid
  *                    (whole 128-pixel tiles; pix_count 0 = to the end); schedule 0 = pick, 1 = one block
  *                    per tile, 2 = persistent stream-K.  With a workspace of
@@ -94,10 +100,13 @@ int dasac_conv_table(const int32_t* kh, const int32_t* kw, const int32_t* dil, c
                      int32_t* table, dasac_stream_t stream);
 int dasac_conv_pack(const float* w, const float* scale, int Cout, int Cin, int taps, int tap0,
                     int total_taps, int transposed, int order, float* packed, dasac_stream_t stream);
+size_t dasac_relu_bits_words(int M, int64_t Npix);
+int dasac_conv_gemm_bits_ok(int M, int Cx);   /* 1: dasac_conv_gemm takes mask_bits / relu_bits_out for this (M, gathered channels) */
 int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, float* out,
                     int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                     int OutH, int OutW, int ostride,
                     const float* shift, const float* res, const float* mask,
+                    const uint32_t* mask_bits, uint32_t* relu_bits_out,
                     int relu, int pix_begin, int pix_count, int schedule,
                     void* workspace, size_t ws_bytes, dasac_stream_t stream);
 /* Split-bf16 ("bf16x3") variant of the same contraction: every fp32 operand x is split into
@@ -112,6 +121,7 @@ int dasac_conv_gemm_x3(const float* x, const void* packed_x3, const int32_t* tab
                        int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                        int OutH, int OutW, int ostride,
                        const float* shift, const float* res, const float* mask,
+                       const uint32_t* mask_bits, uint32_t* relu_bits_out,
                        int relu, int pix_begin, int pix_count, int schedule,
                        void* workspace, size_t ws_bytes, dasac_stream_t stream);
 size_t dasac_conv_gemm_workspace(void);

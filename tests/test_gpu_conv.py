@@ -226,3 +226,54 @@ def test_whole_network_refresh_equals_the_per_layer_folds_and_packs():
         assert calls == ["pack"]
     finally:
         ops.conv_pack, ops.bn_fold = real_pack, real_fold
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,shape", [
+    (64, 256, 1, 1, (2, 25, 33)),          # 1650 pixels: a ragged last word, a ragged last tile
+    (32, 200, 3, 2, (3, 19, 23)),          # M = 200 -> padded to 256: whole 8-row groups beyond M
+    (48, 130, 3, 1, (1, 31, 17)),          # M % 8 != 0: per-lane row test
+    (256, 256, 3, 2, (8, 97, 97)),         # the layer3 3x3 at its cfg-3 size: leading rounds + stream-K remainder launches
+])
+def test_relu_bit_masks_equal_the_fp32_pattern(cin, cout, k, dil, shape):
+    """ReLU patterns as one bit per element (dasac_conv_gemm relu_bits_out / mask_bits): the forward epilogue's bits are exactly
+    (out > 0) in the documented layout, and a data-gradient GEMM masked by the bits equals the one masked by the fp32 activation
+    bit for bit -- the round-3 replacement for reading a whole activation back just to test its sign."""
+    from dasac_hip import ops
+    N_, H, W = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    spec = ops.ConvSpec(cin, cout, [(k, k, dil, dil * (k // 2))], 1)
+    assert ops.bits_ok(cout, cin) and ops.bits_ok(cin, cout) == (cin > 64 and cout % 16 == 0)
+    x = torch.randn(N_, cin, H, W, generator=g).cuda()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda()
+    shift = torch.randn(cout, generator=g).cuda() * 0.1
+    order = ops.gemm_order(spec, False)
+    table, packed = ops.conv_table(spec, H, W, False, x.device, order), ops.conv_pack(spec, [w], False, None, order=order)
+    y0 = torch.empty(N_, cout, H, W, device="cuda")
+    ops.conv_gemm(x, packed, table, y0, (H, W), 1, cout, spec.K, 1, shift, None, None, True)
+    y1 = torch.empty_like(y0)
+    bits = ops.ReluBits(N_, cout, H, W, x.device)
+    bits.words.fill_(0x55555555)
+    ops.conv_gemm(x, packed, table, y1, (H, W), 1, cout, spec.K, 1, shift, None, None, True, bits_out=bits)
+    assert torch.equal(y0, y1)
+    npix = N_ * H * W
+    w32 = (npix + 31) // 32
+    pos = (y1 > 0).permute(1, 0, 2, 3).reshape(cout, npix)                   # [m][flattened (n, oh, ow)]
+    pad = torch.zeros(cout, w32 * 32 - npix, dtype=torch.bool, device="cuda")
+    want = torch.cat([pos, pad], 1).view(cout, w32, 32).to(torch.int64)
+    want = (want << torch.arange(32, device="cuda")).sum(-1)
+    got = bits.words.view(cout, w32).to(torch.int64) & 0xFFFFFFFF
+    valid = torch.full((w32,), 0xFFFFFFFF, dtype=torch.int64, device="cuda")
+    if npix % 32:
+        valid[-1] = (1 << (npix % 32)) - 1                                   # bits past the last pixel are unspecified
+    assert torch.equal(got & valid, want & valid)
+    assert 0.2 < float(pos.float().mean()) < 0.8
+    # consumer: a 1x1 data-gradient GEMM into this tensor's shape, masked by bits vs by the activation itself
+    if ops.bits_ok(cout, 64):
+        spec2 = ops.ConvSpec(cout, 64, [(1, 1, 1, 0)], 1)
+        w2 = (torch.randn(64, cout, 1, 1, generator=g) / cout ** 0.5).cuda()
+        dz = torch.randn(N_, 64, H, W, generator=g).cuda()
+        res = torch.randn(N_, cout, H, W, generator=g).cuda()
+        a = ops.conv_dgrad(spec2, dz, [w2], (H, W), res=res, mask=y1)
+        b = ops.conv_dgrad(spec2, dz, [w2], (H, W), res=res, mask=bits)
+        assert torch.equal(a, b)
+        assert float((a == 0).float().mean()) > 0.2

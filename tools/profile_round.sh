@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-alt"
+B="python $R/bench.py --no-cpu-baseline --no-kernel-table"
 python $R/bench.py > $O/bench.json 2> $O/bench.err   # stdout = the one JSON line
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o kt -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 python $R/tools/rocpd_stats.py /tmp/p1/kt_results.db > $O/kernel_stats.md

@@ -22,7 +22,7 @@ for cin, k in ((256, 1), (512, 1), (1024, 1), (2048, 1), (256, 3), (512, 3)):
 
     def run(pb, pc, sched):
         L.check(lib.dasac_conv_gemm(x.data_ptr(), pk.data_ptr(), tab.data_ptr(), y.data_ptr(), B, cin, H, W, H, W, 1, cout, spec.K, H, W, 1,
-                                    0, 0, 0, 0, pb, pc, sched, ws.data_ptr(), ws.numel(), L.stream_ptr()), "gemm")
+                                    0, 0, 0, 0, 0, 0, pb, pc, sched, ws.data_ptr(), ws.numel(), L.stream_ptr()), "gemm")
     t_lead = timeit(lambda: run(0, lead, 1), 20)
     t_sk = timeit(lambda: run(lead, 0, 2), 20)
     t_tail_plain = timeit(lambda: run(lead, 0, 1), 20)
