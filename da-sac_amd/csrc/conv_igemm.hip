@@ -515,7 +515,8 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
           asm volatile("" ::: "memory");
         }
         if constexpr (BITS == 1) {
-          if (lane < 32 && mrow + lane < g.M) ep.obits[(size_t)(mrow + lane) * ep.w32 + wcol] = (unsigned)bitrows;
+          // (a 32-pixel group of the last tile may lie entirely past the last pixel: no word exists for it)
+          if (lane < 32 && mrow + lane < g.M && wcol < ep.w32) ep.obits[(size_t)(mrow + lane) * ep.w32 + wcol] = (unsigned)bitrows;
         }
       }
     }

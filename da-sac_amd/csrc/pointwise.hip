@@ -127,6 +127,37 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy,
     if (iw0 + pad - k + 1 < 0) ow_lo = 0;
     const size_t ob = (size_t)plane * OH * OW;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KT > 0 && ST > 0) {
+      // compile-time window / stride: at most NR x NC windows can have picked one of the four pixels.  ALL their argmax
+      // codes, pooled values and gradients are loaded first (clamped addresses, one batch in flight), then routed -- the
+      // runtime-bounded loop below serialises three dependent loads per window.
+      constexpr int NR = (KT + ST - 1) / ST, NC = (3 + KT + ST - 1) / ST;
+      int code[NR][NC];
+      float yv[NR][NC], dv[NR][NC];
+#pragma unroll
+      for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int b = 0; b < NC; ++b) {
+          const size_t o = ob + (size_t)min(oh_lo + a, OH - 1) * OW + min(ow_lo + b, OW - 1);
+          code[a][b] = arg[o];
+          dv[a][b] = dy[o];
+          yv[a][b] = relu_mask ? y[o] : 1.f;
+        }
+#pragma unroll
+      for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int b = 0; b < NC; ++b) {
+          const int oh = oh_lo + a, ow = ow_lo + b;
+          const int r = oh * s - pad + code[a][b] / k, c = ow * s - pad + code[a][b] % k - iw0;
+          if (oh <= oh_hi && ow <= ow_hi && r == ih && (unsigned)c < 4u && yv[a][b] > 0.f) {
+            const float d = dv[a][b];
+            g[0] += c == 0 ? d : 0.f;
+            g[1] += c == 1 ? d : 0.f;
+            g[2] += c == 2 ? d : 0.f;
+            g[3] += c == 3 ? d : 0.f;
+          }
+        }
+    } else {
     for (int oh = oh_lo; oh <= oh_hi; ++oh)
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
         const size_t o = ob + (size_t)oh * OW + ow;
@@ -140,6 +171,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy,
           g[3] += c == 3 ? d : 0.f;
         }
       }
+    }
     float* out = dx + (size_t)row * W + iw0;
     if (nx == 4) {
       *reinterpret_cast<f32x4u*>(out) = f32x4u{g[0], g[1], g[2], g[3]};

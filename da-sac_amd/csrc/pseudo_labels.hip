@@ -13,30 +13,80 @@ constexpr int kPlBlock = 256;
 constexpr int kPlMaxC = 64;
 
 // All probabilities are >= +0, so the IEEE bit pattern is monotone as a signed int.
-__global__ __launch_bounds__(kPlBlock) void pl_argmax_peaks(const float* __restrict__ probs, int C, int64_t HW,
+// FOUR consecutive pixels per thread: every class plane is one (4-byte aligned) dwordx4 load, and with the compile-time class
+// count CT (19: the reference's NUM_CLASSES; 0 = runtime count, loads four classes at a time) all of a thread's plane loads
+// are in flight together; max_conf leaves as one dwordx4 store, the four argmax bytes as one dword.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int CT>
+__global__ __launch_bounds__(kPlBlock) void pl_argmax_peaks(const float* __restrict__ probs, int Crt, int64_t HW,
                                                             int blocks_per_image, float* __restrict__ max_conf,
                                                             uint8_t* __restrict__ arg8, int* __restrict__ peaks) {
   __shared__ int s_peak[kPlMaxC];
+  const int C = CT ? CT : Crt;
   const int b = blockIdx.x / blocks_per_image;
   const int chunk = blockIdx.x % blocks_per_image;
   if (threadIdx.x < kPlMaxC) s_peak[threadIdx.x] = 0;
   __syncthreads();
   const float* img = probs + (int64_t)b * C * HW;
-  const int64_t stride = (int64_t)blocks_per_image * kPlBlock;
-  for (int64_t p = (int64_t)chunk * kPlBlock + threadIdx.x; p < HW; p += stride) {
-    float m = img[p];
-    int k = 0;
-    for (int c = 1; c < C; ++c) {
-      float v = img[(int64_t)c * HW + p];
-      if (v > m) {  // strict: ties keep the lowest class (ATen max over dim)
-        m = v;
-        k = c;
+  const int64_t stride = (int64_t)blocks_per_image * kPlBlock * 4;
+  for (int64_t p = ((int64_t)chunk * kPlBlock + threadIdx.x) * 4; p < HW; p += stride) {
+    const int nx = (int)(HW - p < 4 ? HW - p : 4);
+    float m[4];
+    int k[4] = {0, 0, 0, 0};
+    if (nx == 4) {
+      if (CT) {
+        f32x4u v[CT ? CT : 1];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) v[c] = *reinterpret_cast<const f32x4u*>(img + (int64_t)c * HW + p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v[0][e];
+#pragma unroll
+        for (int c = 1; c < CT; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (v[c][e] > m[e]) {  // strict: ties keep the lowest class (ATen max over dim)
+              m[e] = v[c][e];
+              k[e] = c;
+            }
+      } else {
+        const f32x4u v0 = *reinterpret_cast<const f32x4u*>(img + p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v0[e];
+#pragma unroll 4
+        for (int c = 1; c < C; ++c) {
+          const f32x4u v = *reinterpret_cast<const f32x4u*>(img + (int64_t)c * HW + p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (v[e] > m[e]) {
+              m[e] = v[e];
+              k[e] = c;
+            }
+        }
       }
+      *reinterpret_cast<f32x4u*>(max_conf + (int64_t)b * HW + p) = f32x4u{m[0], m[1], m[2], m[3]};
+    } else {                                   // the last, partial quad of an image
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (e < nx) {
+          m[e] = img[p + e];
+          for (int c = 1; c < C; ++c) {
+            const float v = img[(int64_t)c * HW + p + e];
+            if (v > m[e]) {
+              m[e] = v;
+              k[e] = c;
+            }
+          }
+          max_conf[(int64_t)b * HW + p + e] = m[e];
+        }
     }
-    max_conf[(int64_t)b * HW + p] = m;
-    arg8[(int64_t)b * HW + p] = (uint8_t)k;
-    const int mi = __float_as_int(m);
-    if (mi > s_peak[k]) atomicMax(&s_peak[k], mi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < nx) {
+        arg8[(int64_t)b * HW + p + e] = (uint8_t)k[e];
+        const int mi = __float_as_int(m[e]);
+        if (mi > s_peak[k[e]]) atomicMax(&s_peak[k[e]], mi);
+      }
   }
   __syncthreads();
   if (threadIdx.x < C) {
@@ -94,7 +144,11 @@ extern "C" int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, co
   hipStream_t s = as_stream(stream);
   DASAC_HIP(hipMemsetAsync(peaks, 0, (size_t)B * C * sizeof(int), s));
   int per_image = stream_grid(HW, kPlBlock, (kNumCu * 16 + B - 1) / B);
-  hipLaunchKernelGGL(pl_argmax_peaks, dim3(per_image * B), dim3(kPlBlock), 0, s, probs, C, HW, per_image, max_conf, arg8, peaks);
+  const int per_image4 = stream_grid((HW + 3) / 4, kPlBlock, (kNumCu * 16 + B - 1) / B);      // four pixels per thread
+  if (C == 19)
+    hipLaunchKernelGGL(pl_argmax_peaks<19>, dim3(per_image4 * B), dim3(kPlBlock), 0, s, probs, C, HW, per_image4, max_conf, arg8, peaks);
+  else
+    hipLaunchKernelGGL(pl_argmax_peaks<0>, dim3(per_image4 * B), dim3(kPlBlock), 0, s, probs, C, HW, per_image4, max_conf, arg8, peaks);
   DASAC_CHECK_LAUNCH("pl_argmax_peaks");
   hipLaunchKernelGGL(pl_threshold, dim3(per_image * B), dim3(kPlBlock), 0, s, max_conf, arg8, ignore, peaks, disc, upper,
                      lower, C, HW, per_image, labels, max_idx);
