@@ -156,15 +156,16 @@ def test_ddp_buffer_broadcast_does_not_repack_frozen_networks():
         import driver
         src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=3)
         calls = []
-        real = ops.conv_pack
+        real, real_all = ops.conv_pack, ops.refresh_network           # per-layer packs and the whole-network refresh
         ops.conv_pack = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        ops.refresh_network = lambda *a, **k: (calls.append(1), real_all(*a, **k))[1]
         try:
             with torch.no_grad():
                 ddp(tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4], use_teacher=True, update_teacher=True, T=2)
                 first = len(calls)
                 ddp(tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4], use_teacher=True, update_teacher=False, T=2)
         finally:
-            ops.conv_pack = real
+            ops.conv_pack, ops.refresh_network = real, real_all
         assert first > 0 and len(calls) == first, (first, len(calls))
     finally:
         dist.destroy_process_group()
