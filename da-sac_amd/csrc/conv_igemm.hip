@@ -1344,6 +1344,9 @@ extern "C" int dasac_conv_pack_x3(const float* packed, int M, int K, void* packe
 // whose block total fills whole rounds of resident blocks (2 per CU for the 128-row tile, 3 otherwise).
 static int wgrad_bn(int Cx) { return (Cx % 128 != 0 && Cx % 64 == 0) ? 64 : 128; }   // k-tile rows: one tap per tile when possible
 
+// 3 resident blocks per CU (<= 168 registers).  Measured in round 3: both 128x128 kernels also fit 128 registers (2 / 44 spill
+// instructions outside the MFMA loop) and 4 x 36 KB of LDS, but at 4 blocks per CU the step's weight-gradient time goes from
+// 109.2 to 114.0 ms (123.1 -> 117.9 TFLOP/s): occupancy is not what the pixel loop lacks.
 static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM, int BNk = 128) {
   const int tiles = (Mpad / BM) * (Kpad / BNk);
   const int slots = kNumCu * 3;
