@@ -19,8 +19,9 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS
 python $R/tools/pmc_clock.py /tmp/p2/p_results.db > $O/pmc_clock_mfma.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p3 -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p4 -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
-python $R/tools/hbm_traffic.py /tmp/p3/p_results.db /tmp/p4/p_results.db > $O/hbm_traffic.md
+python $R/tools/hbm_traffic.py /tmp/p3/p_results.db /tmp/p4/p_results.db --json $O/traffic.json > $O/hbm_traffic.md
 cat $O/bench.json
 head -6 $O/kernel_stats.md | cut -c1-150
 head -6 $O/pmc_clock_mfma.txt
-head -6 $O/hbm_traffic.md | cut -c1-170
+cat $O/hbm_traffic.md | cut -c1-170
+python $R/tools/step_shapes.py 2 > $O/step_shapes.txt 2>/dev/null; head -40 $O/step_shapes.txt

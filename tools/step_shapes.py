@@ -26,7 +26,7 @@ sys.stdout = out
 
 def step(i):
     tgt_i = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])
-    return driver.sac_train_iteration(net, opt, src, tgt_i, 4, update_teacher=(i == 0), lr_target=cfg.LR_TARGET)
+    return driver.sac_train_iteration(net, opt, src, tgt_i, 4, update_teacher=(i == 0), lr_target=cfg.LR_TARGET, fuse_passes=True)
 
 
 step(0)
