@@ -542,9 +542,7 @@ constexpr int kWgPitch = 36;   // row pitch (floats): 16-byte aligned rows, 16 c
 // gives the head as an fp32 bit pattern directly) and stored with 16-bit writes into [octet of 8 pixels][row][8]
 // operand words; the octet pitch rows+2 keeps the 64 lanes of a store on distinct banks and the 16-byte MFMA
 // operand reads of consecutive rows contiguous.
-// AQUAD: the dZ operand alone through the four-pixels-per-lane loader (dZ is a plain [row][pixel] matrix for ANY kernel size,
-// stride or dilation; the gathered operand keeps one pixel per lane: its tap shifts break 16-byte runs at every image row).
-template <int BM, int BN, int WAVES_M, bool FAST, bool X3, bool QUAD = false, bool AQUAD = false>
+template <int BM, int BN, int WAVES_M, bool FAST, bool X3, bool QUAD = false>
 __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
                                                        float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
@@ -698,21 +696,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
       }
     }
   } else {
-  static_assert(!AQUAD || (FAST && !X3 && BM % 32 == 0), "dZ quad loader: fp32, scalar row offsets, 32-row passes");
   float ra[A_LOADS], rb[B_LOADS];
   float rsum[A_LOADS];                                   // per-row sums of dZ (only the k_tile 0 blocks)
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) rsum[i] = 0.f;
   const int zimg = g.M * OHW;                            // dZ image stride
-  // AQUAD: this thread's dZ quad (pixel quad pq of the step, row prow4 of a 32-row pass) and its own flat pixel cursor
-  constexpr int AQ = BM / 32;
-  const int pq = t & 7, prow4 = t >> 3;
-  f32x4 qa[AQUAD ? AQ : 1];
-  float qsum[AQUAD ? AQ : 1];
-#pragma unroll
-  for (int i = 0; i < (AQUAD ? AQ : 1); ++i) qsum[i] = 0.f;
-  int apix = p_begin + 4 * pq;
-  int apn = apix / OHW, aprr = apix - apn * OHW;
 
   // pixel cursor of this thread (advanced by kWgPix per step)
   int pix = p_begin + pl;
@@ -726,29 +714,6 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     const int ih0 = poh * g.stride, iw0 = pow_ * g.stride;                                           \
     const int xbase = pn * g.CxHW + ih0 * g.W + iw0;                                                 \
     if (FAST) {                                                                                      \
-      if constexpr (AQUAD) {                                                                         \
-        /* quads that leave the split or straddle two images: the whole wave takes the per-element path */ \
-        /* this step; rows past M (partial last M tile) read whatever lies there -- their products land */ \
-        /* in slab rows >= M that nobody reads                                                        */ \
-        const bool whole = (apix + 3 < p_end) & (aprr + 3 < OHW);                                    \
-        if (__builtin_amdgcn_ballot_w64(!whole) == 0) {                                              \
-          const unsigned vq = (unsigned)(apn * zimg + aprr + prow4 * OHW) * 4u;                      \
-          _Pragma("unroll") for (int i = 0; i < AQ; ++i) qa[i] = buf_f32x4(rz, vq, (m0 + i * 32) * OHW * 4); \
-        } else {                                                                                     \
-          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-            int re = aprr + e, ne = apn;                                                             \
-            while (re >= OHW) { re -= OHW; ++ne; }                                                   \
-            const unsigned vq = (apix + e < p_end) ? (unsigned)(ne * zimg + re + prow4 * OHW) * 4u : kPoison; \
-            _Pragma("unroll") for (int i = 0; i < AQ; ++i) qa[i][e] = buf_f32(rz, vq, (m0 + i * 32) * OHW * 4); \
-          }                                                                                          \
-        }                                                                                            \
-        if (do_sums) {                                                                               \
-          _Pragma("unroll") for (int i = 0; i < AQ; ++i) qsum[i] += (qa[i].x + qa[i].y) + (qa[i].z + qa[i].w); \
-        }                                                                                            \
-        apix += kWgPix;                                                                              \
-        aprr += kWgPix;                                                                              \
-        while (aprr >= OHW) { aprr -= OHW; ++apn; }                                                  \
-      } else {                                                                                       \
       const unsigned vz = pv ? (unsigned)(zbase + prow * OHW) * 4u : kPoison;                        \
       /* rows past M (last, partial M tile) re-read the last valid 8-row group: their products land */ \
       /* in slab rows >= M that nobody reads -- no per-row branch or select in the loop            */ \
@@ -756,7 +721,6 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
         ra[i] = buf_f32(rz, vz, min(m0 + i * 8, g.M - 8) * OHW * 4);                                 \
       if (do_sums) {                                                                                 \
         _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) rsum[i] += ra[i];                        \
-      }                                                                                              \
       }                                                                                              \
       const int ih = ih0 + e0.y, iw = iw0 + e0.z;                                                    \
       const bool ok = pv & ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);          \
@@ -799,12 +763,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
       b16[32 * PB + e] = (unsigned short)(l >> 16);                                                  \
     }                                                                                                \
   } else {                                                                                           \
-    if constexpr (AQUAD) {                                                                           \
-      _Pragma("unroll") for (int i = 0; i < AQ; ++i)                                                 \
-        *reinterpret_cast<f32x4*>(&sA[buf][(prow4 + i * 32) * kWgPitch + 4 * pq]) = qa[i];           \
-    } else {                                                                                         \
-      _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) sA[buf][(prow + i * 8) * kWgPitch + pl] = ra[i]; \
-    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) sA[buf][(prow + i * 8) * kWgPitch + pl] = ra[i]; \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) sB[buf][(prow + i * 8) * kWgPitch + pl] = rb[i]; \
   }
 
@@ -870,16 +829,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
 #undef DASAC_WG_LOAD
 #undef DASAC_WG_STORE
 
-  if (do_sums && AQUAD) {
-    // the 8 lanes of a row hold its 32 pixels (4 each): butterfly over the three low lane bits
-#pragma unroll
-    for (int i = 0; i < (AQUAD ? AQ : 1); ++i) {
-      float v = qsum[i];
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (pq == 0) Psum[(size_t)split * g.Mpad + m0 + prow4 + i * 32] = v;
-    }
-  } else if (do_sums) {
+  if (do_sums) {
     // the 32 lanes of a half-wave hold the 32 pixels of the same rows: butterfly inside the half
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
@@ -1396,7 +1346,9 @@ static int wgrad_bn(int Cx) { return (Cx % 128 != 0 && Cx % 64 == 0) ? 64 : 128;
 
 // 3 resident blocks per CU (<= 168 registers).  Measured in round 3: both 128x128 kernels also fit 128 registers (2 / 44 spill
 // instructions outside the MFMA loop) and 4 x 36 KB of LDS, but at 4 blocks per CU the step's weight-gradient time goes from
-// 109.2 to 114.0 ms (123.1 -> 117.9 TFLOP/s): occupancy is not what the pixel loop lacks.
+// 109.2 to 114.0 ms (123.1 -> 117.9 TFLOP/s): occupancy is not what the pixel loop lacks.  Nor is it the dZ loads of the 3x3
+// layers: dZ through the four-pixels-per-lane loader (dwordx4 + ds_write_b128, the gathered operand unchanged) gives 109.6 vs
+// 109.1 ms.
 static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM, int BNk = 128) {
   const int tiles = (Mpad / BM) * (Kpad / BNk);
   const int slots = kNumCu * 3;
@@ -1456,18 +1408,11 @@ static int conv_wgrad_impl(bool x3, const float* dz, const float* x, const int32
     case 128: {
       // 1x1 stride-1 layers: both operands are plain [row][pixel] matrices -> four pixels per lane (conv_wgrad<..., QUAD>)
       static const int quad_mode = getenv("DASAC_WGRAD_QUAD") ? atoi(getenv("DASAC_WGRAD_QUAD")) : 1;
-      static const int aquad_mode = getenv("DASAC_WGRAD_AQUAD") ? atoi(getenv("DASAC_WGRAD_AQUAD")) : 1;
       const bool quad = quad_mode && fast && !x3 && K == Cx && stride == 1 && H == OH && W == OW && M % 128 == 0;   // one tap, no padding
       if (quad) {
         const int m_tiles = g.Mpad / 128, k_tiles = g.Kpad / 128;
         const int grid = (m_tiles * k_tiles * splits + kNumXcd - 1) / kNumXcd * kNumXcd;
         hipLaunchKernelGGL((conv_wgrad<128, 128, 2, true, false, true>), dim3(grid), dim3(kThreads), 0, s, dz, x, tab, P, Psum, g,
-                           m_tiles, k_tiles, splits, per);
-      } else if (fast && !x3 && aquad_mode) {
-        // every other one-tap-per-tile layer (3x3, strided 1x1): the dZ operand through the quad loader
-        const int m_tiles = g.Mpad / 128, k_tiles = g.Kpad / 128;
-        const int grid = (m_tiles * k_tiles * splits + kNumXcd - 1) / kNumXcd * kNumXcd;
-        hipLaunchKernelGGL((conv_wgrad<128, 128, 2, true, false, false, true>), dim3(grid), dim3(kThreads), 0, s, dz, x, tab, P, Psum, g,
                            m_tiles, k_tiles, splits, per);
       } else if (fast) launch_wgrad<128, 128, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       else launch_wgrad<128, 128, 2, false>(x3, dz, x, tab, P, Psum, g, splits, per, s);

@@ -20,10 +20,10 @@ CASES = [
     ("1x1_quad", 256, 256, [(1, 1, 1, 0)], 1, (2, 25, 33)),
     ("3x3_d2", 32, 64, [(3, 3, 2, 2)], 1, (2, 19, 23)),
     ("3x3_d4_big", 128, 128, [(3, 3, 4, 4)], 1, (1, 33, 31)),
-    # the dZ-quad weight-gradient loader (conv_wgrad<..., AQUAD>: one tap per k tile, 128-row M tiles): 9x13 = 117 pixels per image
-    # (quads straddle images), a partial last M tile (200 of 256 rows), and a strided 1x1 (dZ grid != input grid)
-    ("3x3_d2_aquad_ragged", 128, 200, [(3, 3, 2, 2)], 1, (3, 9, 13)),
-    ("1x1_s2_aquad", 128, 256, [(1, 1, 1, 0)], 2, (2, 25, 33)),
+    # one tap per k tile with 128-row M tiles (the layer3 / layer4 weight-gradient path): a partial last M tile (200 of 256 rows)
+    # over 117-pixel images, and a strided 1x1 (dZ grid != input grid)
+    ("3x3_d2_fast_ragged", 128, 200, [(3, 3, 2, 2)], 1, (3, 9, 13)),
+    ("1x1_s2_fast", 128, 256, [(1, 1, 1, 0)], 2, (2, 25, 33)),
     ("3x3_d1_c19", 48, 19, [(3, 3, 1, 1)], 1, (3, 9, 13)),
     ("7x7_s2_stem", 3, 64, [(7, 7, 1, 3)], 2, (2, 65, 49)),
     ("aspp4", 96, 19, [(3, 3, 6, 6), (3, 3, 12, 12), (3, 3, 18, 18), (3, 3, 24, 24)], 1, (2, 17, 21)),

@@ -21,9 +21,8 @@ HOT = {
     "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi1EEE": 168,
     "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi2EEE": 128,      # tile-per-block, epilogue masks with a recorded bit mask
     "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi2EEE": 168,
-    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb0ELb0EEE": 168,
-    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb1ELb0EEE": 168,        # QUAD: four pixels per lane, both operands (1x1 stride-1 layers)
-    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb0ELb1EEE": 168,        # AQUAD: four pixels per lane for dZ only (3x3, strided 1x1)
+    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb0EEE": 168,
+    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb1EEE": 168,        # QUAD: four pixels per lane (1x1 stride-1 layers)
 }
 
 
