@@ -260,6 +260,28 @@ class Engine:
             self._packs[slot] = ent
         return ent[1]
 
+    def largest_tensor_bytes(self, Nb, H, W):
+        """Bytes of the largest activation (or expanded-conv intermediate) a pass over an [Nb, *, H, W] input creates.  The conv
+        kernels address tensors through 32-bit buffer descriptors: every one of them has to stay below 2 GiB."""
+        shapes = {0: (None, H, W)}
+        biggest = 0
+        for op in self.plan.ops:
+            _, h, w = shapes[op.src]
+            if op.kind == "conv":
+                oh, ow = op.spec.out_hw(h, w)
+                c = op.spec.cout
+                if op.expanded is not None:
+                    biggest = max(biggest, Nb * op.expanded.E * oh * ow * 4)
+            elif op.kind == "pool":
+                oh, ow, c = ops.pool_out(h, op.k, op.s, op.p, op.ceil), ops.pool_out(w, op.k, op.s, op.p, op.ceil), shapes[op.src][0]
+            elif op.kind == "up2add":
+                oh, ow, c = 2 * h, 2 * w, shapes[op.src][0]
+            else:
+                oh, ow, c = h, w, shapes[op.src][0]
+            shapes[op.dst] = (c, oh, ow)
+            biggest = max(biggest, Nb * (c or 1) * oh * ow * 4)
+        return biggest
+
     # ---------------------------------------------------------------- whole-network refresh of folds / packs
     def _refresh_plan(self, device, transposed):
         """Device job tables for `ops.refresh_network`: one fold job per frozen-BN conv, one pack job per (conv, layout) for

@@ -124,9 +124,12 @@ def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_tea
     loss_ce + LR_TARGET * self_ce (`SAC.forward_fused`: same weights in both passes, frozen BN, teacher independent of the
     student -- the same gradient sum, half the launches, one gradient all-reduce per iteration).  Needs the bare module or
     `dasac_hip.parallel.OverlappedDataParallel`; silently runs the two-pass order where it does not apply (target_only, stock
-    DistributedDataParallel, batch-statistics BN)."""
+    DistributedDataParallel, batch-statistics BN, crops of different sizes, or a concatenated batch whose largest activation
+    would leave the kernels' 2 GiB addressing window -- FCN-8s at 16 crops of 512x1024)."""
     core = net.module if hasattr(net, "module") else net
-    if fuse_passes and not target_only and hasattr(net, "forward_fused") and hasattr(core, "backbone") and core.backbone._bn_frozen():
+    if fuse_passes and not target_only and hasattr(net, "forward_fused") and hasattr(core, "backbone") and core.backbone._bn_frozen() \
+            and tuple(src_batch[0].shape[1:]) == tuple(tgt_batch[0].shape[1:]) \
+            and core.backbone._batch_fits(src_batch[0].shape[0] + tgt_batch[0].shape[0], *src_batch[0].shape[-2:]):
         images, masks = src_batch
         frames1, frames_gt, frames2, affine, affine_inv = tgt_batch
         losses_src, losses_tgt, outs = net.forward_fused(images, masks, frames1, frames_gt, frames2, affine, affine_inv,

@@ -107,6 +107,12 @@ class BaseNet(nn.Module):
         """True when every BN of the net runs in eval mode (SAC mode / inference)."""
         return all(not m.training for m in self.modules() if isinstance(m, BaseNet._batchnorm))
 
+    def _batch_fits(self, Nb, H, W):
+        """True when a pass over Nb crops of H x W keeps every activation inside the kernels' 2 GiB addressing window."""
+        if self._engine is None or self._engine.stale():
+            self._engine = E.Engine(self._plan())
+        return self._engine.largest_tensor_bytes(Nb, H, W) < (1 << 31)
+
     def _logits(self, im):
         if self._engine is None or self._engine.stale():      # parameter objects replaced -> re-capture the plan
             self._engine = E.Engine(self._plan())
