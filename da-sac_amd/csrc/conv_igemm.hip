@@ -80,6 +80,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int b
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+
 // agent-scope (sc1) 16-byte accesses for data handed from one workgroup to another inside a launch: an sc1 store is
 // written through to memory, an sc1 load does not hit a stale line of this XCD's L2 / this CU's L1 -- the per-XCD L2s
 // are not coherent with each other (MI355X_MICROARCH.md, inter-workgroup visibility).  With both sides sc1 the hand-off

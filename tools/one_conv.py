@@ -14,6 +14,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 cin, cout, br, stride, H, W = SH[name]
 spec = ops.ConvSpec(cin, cout, br, stride)
+torch.manual_seed(0)
 x = torch.randn(B, cin, H, W, device="cuda")
 ws = [torch.randn(cout, cin, b[0], b[1], device="cuda") * 0.05 for b in br]
 OH, OW = spec.out_hw(H, W)
@@ -42,7 +43,15 @@ else:
     tab = ops.conv_table(spec, H, W, False, x.device, 0)
     alg = MB(dz, x) + sum(MB(w) for w in ws)
     run = lambda: ops.conv_wgrad(spec, dz, x, ws, table=tab)
+run()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
 for _ in range(iters):
     run()
+b.record()
 torch.cuda.synchronize()
-print("done {} {} B={} algorithmic_MB_per_launch {:.1f}".format(name, mode, B, alg))
+out = run()
+out = out[0] if isinstance(out, (list, tuple)) else out
+print("done {} {} B={} algorithmic_MB_per_launch {:.1f} us_per_call {:.1f} checksum {:.6e} {:.6e}".format(
+    name, mode, B, alg, a.elapsed_time(b) * 1e3 / iters, float(out.double().sum()), float(out.double().abs().sum())))
