@@ -33,6 +33,18 @@ constexpr int kInvalid = 1 << 20;  // dh of a padded table row: never in bounds
 constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
 constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8: the grid of every stream-K launch
 
+#ifdef DASAC_TRACE_TILES
+// Diagnostic build only (tools/tile_timeline.py): per tile-per-block workgroup four s_memtime stamps -- start, first tile in LDS,
+// end of the K loop, end of the epilogue -- plus the hardware XCC / CU ids.  Never part of the shipped library.
+__device__ unsigned long long* g_tile_trace = nullptr;
+__device__ __forceinline__ void trace_stamp(int slot) {
+  if (g_tile_trace && threadIdx.x == 0) g_tile_trace[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
+#define DASAC_STAMP(slot) trace_stamp(slot)
+#else
+#define DASAC_STAMP(slot)
+#endif
+
 struct GemmGeom {
   // gathered tensor X [Nb, Cx, H, W]
   int H, W, CxHW;                // CxHW = Cx*H*W (image stride)
@@ -317,9 +329,11 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    DASAC_STAMP(0);
     DASAC_LOAD_TILE(ks);
     DASAC_STORE_TILE(ks & 1);
     __syncthreads();
+    DASAC_STAMP(1);
     for (int kt = ks; kt < ke; ++kt) {
       const int buf = kt & 1;
       const bool more = kt + 1 < ke;
@@ -453,6 +467,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
     // descriptors: per-lane voffset = pixel position (+ the lane-half's 4-row step), the row offset is
     // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
     const bool deposited = STREAMK && ks > 0;                // this worker only contributed a partial sum
+    DASAC_STAMP(2);
     if (!deposited) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -522,6 +537,11 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
       }
     }
     }
+#ifdef DASAC_TRACE_TILES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have been acknowledged
+    DASAC_STAMP(3);
+    if (g_tile_trace && threadIdx.x == 0) g_tile_trace[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;
+#endif
     if (STREAMK) __syncthreads();      // LDS is reused by the next tile of this worker
   }
 }
@@ -1237,6 +1257,13 @@ extern "C" int dasac_conv_gemm_plan(int Nb, int OH, int OW, int M, int K) {
 extern "C" size_t dasac_conv_gemm_workspace(void) {
   return (size_t)kSkWorkers * 128 * 128 * sizeof(float) + (size_t)(kSkWorkers + 1) * sizeof(int);
 }
+
+#ifdef DASAC_TRACE_TILES
+extern "C" int dasac_debug_set_tile_trace(void* buffer) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buffer);
+  return hipMemcpyToSymbol(HIP_SYMBOL(dasac::g_tile_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t dasac_relu_bits_words(int M, int64_t Npix) { return (size_t)M * (size_t)((Npix + 31) / 32); }
 // 1 when dasac_conv_gemm (fp32) can record / consume bit masks for an output of M channels over a gathered tensor of Cx channels
