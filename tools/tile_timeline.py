@@ -19,8 +19,10 @@ raw = ctypes.CDLL(out)
 name = sys.argv[1] if len(sys.argv) > 1 else "l3_1x1b"
 mode = sys.argv[2] if len(sys.argv) > 2 else "fwd_res"
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+HW_ARG = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # plane side (default 97: cfg-3's stride-8 maps)
 SH = {"l3_3x3": (256, 256, [(3, 3, 2, 2)], 97), "l3_1x1a": (1024, 256, [(1, 1, 1, 0)], 97), "l3_1x1b": (256, 1024, [(1, 1, 1, 0)], 97)}
 cin, cout, br, H = SH[name]
+H = HW_ARG or H
 spec = ops.ConvSpec(cin, cout, br, 1)
 x = torch.randn(B, cin, H, H, device="cuda")
 ws = [torch.randn(cout, cin, b[0], b[1], device="cuda") * 0.05 for b in br]
@@ -37,20 +39,24 @@ a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 a.record(); run(); b.record(); torch.cuda.synchronize()
 t = trace.cpu().numpy().reshape(-1, 8)
 t = t[t[:, 0] > 0]
-t0 = t[:, 0].min()
-span = (t[:, 3].max() - t0)
 us = a.elapsed_time(b) * 1e3
-tick = us / span                     # microseconds per s_memtime tick, from the launch's own duration
-st, ld, kl, ep = (t[:, 0] - t0) * tick, (t[:, 1] - t[:, 0]) * tick, (t[:, 2] - t[:, 1]) * tick, (t[:, 3] - t[:, 2]) * tick
-print("{} {} B={}: {} workgroups, launch {:.1f} us ({:.4f} us/tick)".format(name, mode, B, len(t), us, tick))
+# s_memtime counters of different XCDs have different bases: normalise per XCC, calibrate the tick on the per-XCC launch span
+xcc = t[:, 4].astype(np.int64)
+spans = []
+for c in np.unique(xcc):
+    m = xcc == c
+    base = t[m, 0].min()
+    t[m, :4] -= base
+    spans.append(t[m, 3].max())
+tick = us / float(np.median(spans))
+st, ld, kl, ep = t[:, 0] * tick, (t[:, 1] - t[:, 0]) * tick, (t[:, 2] - t[:, 1]) * tick, (t[:, 3] - t[:, 2]) * tick
+# the counters are not comparable across CUs; only differences inside one workgroup are used below, scaled so that the mean
+# workgroup lifetime equals launch time x resident slots / workgroups (all slots busy)
+life = (t[:, 3] - t[:, 0]).astype(np.float64)
+tick = (us * min(1024, len(t)) / len(t)) / life.mean()
+st, ld, kl, ep = t[:, 0] * tick, (t[:, 1] - t[:, 0]) * tick, (t[:, 2] - t[:, 1]) * tick, (t[:, 3] - t[:, 2]) * tick
+print("{} {} B={} {}x{}: {} workgroups, launch {:.1f} us, {:.1f} TFLOP/s".format(name, mode, B, H, H, len(t), us, 2.0 * B * H * H * cout * spec.K / us / 1e6))
 for nm, v in (("prologue (first tile -> LDS)", ld), ("K loop", kl), ("epilogue (stores acknowledged)", ep), ("whole workgroup", ld + kl + ep)):
     print("  {:32s} mean {:7.2f}  p10 {:7.2f}  p50 {:7.2f}  p90 {:7.2f}  max {:7.2f} us".format(nm, v.mean(), *np.percentile(v, [10, 50, 90]), v.max()))
-# occupancy of the phases over time: how many workgroups sit in prologue / K loop / epilogue at 40 sample times
-ts = np.linspace(0, us, 41)[1:-1]
-print("  time us : in prologue / in K loop / in epilogue  (of {} resident slots)".format(256 * 4))
-for x_ in ts[::3]:
-    tt = x_ / tick + t0
-    print("  {:8.1f} : {:5d} {:5d} {:5d}".format(x_, int(((t[:, 0] <= tt) & (tt < t[:, 1])).sum()), int(((t[:, 1] <= tt) & (tt < t[:, 2])).sum()),
-                                                  int(((t[:, 2] <= tt) & (tt < t[:, 3])).sum())))
-xcc = t[:, 4]
-print("  block id % 8 == hardware XCC id for {:.1f} % of the workgroups".format(100.0 * float((xcc == (np.arange(len(trace) // 8)[trace.cpu().numpy().reshape(-1, 8)[:, 0] > 0] % 8)).mean())))
+print("  sum over workgroups / (launch x 1024 slots): prologue {:.3f}  K loop {:.3f}  epilogue {:.3f}".format(
+    ld.sum() / (us * 1024), kl.sum() / (us * 1024), ep.sum() / (us * 1024)))
