@@ -1,7 +1,9 @@
-"""Full-resolution end-to-end parity (cfg-3's 769x769 crops): the sample bench.py times the CPU oracle on -- 1 source + 1
+"""Full-resolution end-to-end parity.  cfg-3 (769x769 crops): the sample bench.py times the CPU oracle on -- 1 source + 1
 target crop, student forward/backward each, teacher forward, SAC head, SGD step -- runs through the HIP module too and the
-two are compared (losses, label map, class prior, sampled gradients and updated parameters); and `bench.py --gpus 2`
-launches its own ranks (two on the one GPU of the box) and prints the contract's JSON line."""
+two are compared (losses, label map, class prior, sampled gradients and updated parameters), under both student schedules;
+cfg-2 (baseline / AdaBN iteration with batch-statistics BN at 769x769, gradients arbitrated by a float64 oracle run) and cfg-5
+(VGG16-FCN8s + SAC at 512x1024) likewise at their own resolutions; and `bench.py --gpus 2` launches its own ranks (two on the one
+GPU of the box) and prints the contract's JSON line.  The CPU oracle needs 10-60 s per case on the box's host cores."""
 import json
 import os
 import subprocess
