@@ -314,9 +314,8 @@ def main():
             other_sched = repr(exc)[:200]
         schedule["fuse"] = not schedule["fuse"]
         done += 1 + psteps
-    core_net = net
     fused_now = bool(schedule["fuse"]) and not baseline and wrapper != "ddp" and \
-        core_net.backbone._batch_fits(args.batch + args.groups * args.views, hw[0], hw[1])     # else the driver runs the two passes
+        net.backbone._batch_fits(args.batch + args.groups * args.views, hw[0], hw[1])     # else the driver runs the two passes
     alt = None
     if args.alt and not baseline:
         # the same K steps once more in the other arithmetic (outside the contract's timed region; reported as "alt")
