@@ -143,6 +143,126 @@ def parity_fullres(size, device=None, sample=None, fuse=True):
     return (dt, cores), cmp_
 
 
+def head_parity_fullres(size=769, groups=2, views=4, device=None, seed=17):
+    """Full-resolution parity of the MULTI-VIEW head alone (no backbone, so the oracle needs seconds): synthetic teacher logits
+    [groups*views, 19, (size-1)/8+1, ...], the four SURVEY 8d affines per group, padded rows -> `SAC._refine` (upsample +
+    softmax + class prior, warp, L-view fusion, warp back) -> thresholds -> pseudo labels -> `_focal_ce_conf` (the [B,B,H,W]
+    broadcast of sac.py:148 with B = groups*views) value and gradient w.r.t. the student's stride-8 logits, against
+    oracle.head_ref on the same inputs (models/sac.py:134-149,238-313).  Returns (oracle seconds, comparison dict)."""
+    import driver
+    import models
+    from dasac_hip import engine as E, ops
+    from oracle import head_ref as R
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    cfg = model_cfg()
+    B, h = groups * views, (size - 1) // 8 + 1
+    g = torch.Generator().manual_seed(seed)
+    (_, _), (_, gt, frames, theta, theta_inv) = driver.synthetic_batches(1, groups, views, (size, size), "cpu", seed=seed)
+    # teacher logits of a group's views = one blobby scene per group seen through each view's inverse affine (what augmented
+    # views of ONE image look like: the aligned views agree, the fused probabilities are confident and the thresholds fire)
+    coarse = torch.randint(0, 19, (groups, (h + 7) // 8, (h + 7) // 8), generator=g)
+    scene = torch.nn.functional.one_hot(coarse.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :h, :h], 19).permute(0, 3, 1, 2).float() * 8
+    scene = (scene + torch.randn(groups, 19, h, h, generator=g)).repeat_interleave(views, 0)
+    teacher_logits = R.warp_affine(scene, theta_inv) + 0.5 * torch.randn(B, 19, h, h, generator=g)
+    student_logits = teacher_logits * 0.5 + torch.randn(B, 19, h, h, generator=g)
+    ignore = gt == -1
+    chi0 = torch.full((19,), 0.05)
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    # ---- oracle
+    t0 = time.time()
+    refined_r, chi_r, diags_r = R.refine(frames, teacher_logits, views, theta, theta_inv, ignore, chi0.clone(), beta=cfg.THRESHOLD_BETA,
+                                         stat_momentum=cfg.STAT_MOMENTUM, training=True, pool=True, pool_kind=cfg.CONF_POOL)
+    labels_r, conf_r, _ = R.pseudo_labels(refined_r, ignore, cfg.RUN_CONF_UPPER, cfg.RUN_CONF_LOWER, R.threshold_discount(chi_r, cfg.THRESHOLD_BETA))
+    sl_r = student_logits.clone().requires_grad_(True)
+    loss_r, _ = R.focal_ce_conf(R.upsample_bilinear_ac(sl_r, size, size), labels_r, conf_r, chi_r, cfg.FOCAL_P)
+    loss_r.backward()
+    dt = time.time() - t0
+    # ---- HIP module (head methods only; the two backbones are never run)
+    net = models.get_model(cfg, device.index or 0, num_classes=19, criterion=nn.CrossEntropyLoss(**CRITERION))
+    net.to(device).train()
+    net.running_conf.copy_(chi0)
+    net.slow_init[0] = 1.0
+    dev = lambda t: t.to(device)
+    refined, diags = net._refine(dev(frames), dev(teacher_logits), views, dev(theta), dev(theta_inv), dev(ignore), pool=True)
+    disc, fw = net._class_vectors.finish(cfg.THRESHOLD_BETA, cfg.FOCAL_P, cfg.CONF_DISCOUNT)
+    labels, conf, _ = ops.pseudo_labels(refined, dev(ignore), cfg.RUN_CONF_UPPER, cfg.RUN_CONF_LOWER, disc)
+    chi_hip = net.running_conf.detach().cpu().clone()
+    # the integer contract: on EQUAL probabilities (the oracle's, uploaded) and the module's own threshold path
+    net.running_conf.copy_(chi_r)
+    disc_eq, fw_eq = ops.class_vectors(net.running_conf, cfg.THRESHOLD_BETA, cfg.FOCAL_P)
+    labels_eq, conf_eq, _ = ops.pseudo_labels(dev(refined_r), dev(ignore), cfg.RUN_CONF_UPPER, cfg.RUN_CONF_LOWER, disc_eq)
+    # the loss on equal labels / confidences (the oracle's), differentiated down to the stride-8 logits
+    sl = dev(student_logits).requires_grad_(True)
+    loss = E.focal_ce(E.upsample_bilinear(sl, (size, size)), dev(labels_r), fw_eq, dev(conf_r))
+    loss.backward()
+    # and end to end on the HIP side's own labels
+    with torch.no_grad():
+        loss_e2e = E.focal_ce(E.upsample_bilinear(dev(student_logits), (size, size)), labels, fw, conf)
+    torch.cuda.synchronize(device)
+    tmax = lambda a, b: float((a.double().cpu() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    cmp_ = {"size": size, "crops": B, "views_per_group": views,
+            "refined_max_abs": float((refined.cpu() - refined_r).abs().max()),
+            "teacher_aligned_max_abs": float((diags["teacher_aligned"].cpu() - diags_r["teacher_aligned"]).abs().max()),
+            "frames_aligned_rel": tmax(diags["frames_aligned"], diags_r["frames_aligned"]),
+            "running_conf_max_abs": float((chi_hip - chi_r).abs().max()),
+            "labels_equal_on_equal_probs": bool(torch.equal(labels_eq.cpu(), labels_r)),
+            "conf_equal_on_equal_probs": bool(torch.equal(conf_eq.cpu(), conf_r)),
+            "labelled_frac": float((labels_r != 255).double().mean()),
+            "label_mismatch_frac_end_to_end": float((labels.cpu() != labels_r).double().mean()),
+            "self_ce_rel": abs(float(loss) - float(loss_r)) / max(abs(float(loss_r)), 1e-12),
+            "self_ce_rel_end_to_end": abs(float(loss_e2e) - float(loss_r)) / max(abs(float(loss_r)), 1e-12),
+            "dlogits_max_err_over_tensor_max": tmax(sl.grad, sl_r.grad)}
+    return dt, cmp_
+
+
+def time_other_config(config, dev, steps=5, warmup=1):
+    """cfg-2 / cfg-5 of BASELINE.json in the driver-timed process: `steps` un-instrumented steps between
+    fences -> ms_per_step; one more step with HIP events around the GEMM launches -> algorithmic conv TFLOP per step, so that
+    tflops = that / the UN-instrumented step time and frac = tflops / the fp32 matrix peak (whole step, not a kernel)."""
+    import driver
+    import models
+    from dasac_hip import ops
+    if config == "cfg2":
+        arch, baseline, hw, batch, groups, views = "deeplabv2_resnet101", True, (769, 769), 2, 2, 1
+    else:
+        arch, baseline, hw, batch, groups, views = "fcn_vgg16_bn", False, (512, 1024), 8, 2, 4
+    cfg = model_cfg(arch, baseline)
+    net = models.get_model(cfg, dev.index, num_classes=19, criterion=nn.CrossEntropyLoss(**CRITERION))
+    driver.init_synthetic_weights(net, seed=0)
+    net.cuda(dev.index).train()
+    if not baseline:
+        net.running_conf.fill_(0.05)
+    optim = driver.make_optimizer(net, cfg)
+    src, tgt = driver.synthetic_batches(batch, groups, views, hw, dev, seed=0)
+    if arch != "deeplabv2_resnet101":
+        driver.calibrate_classifier(net, src[0][:1])
+    src = (src[0], driver.self_consistent_labels(net, src[0]))
+
+    def step(i):
+        if baseline:
+            return driver.baseline_train_iteration(net, optim, src, tgt[0])
+        t = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])
+        return driver.sac_train_iteration(net, optim, src, t, views, update_teacher=(i == 0), lr_target=cfg.LR_TARGET, fuse_passes=True)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ops.PROFILE.start()
+    step(warmup + steps)
+    prof = ops.PROFILE.stop()
+    tflop = sum(v["flops"] for v in prof.values()) / 1e12
+    return {"ms_per_step": round(ms, 3), "images_per_sec": round(batch / ms * 1e3, 3), "conv_tflop_per_step": round(tflop, 3),
+            "tflops": round(tflop / ms * 1e3, 2), "frac_of_fp32_matrix_peak": round(tflop / ms * 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "workload": "{} source + {}x{} target crops @{}x{}, {}".format(batch, groups, views, hw[0], hw[1],
+                                                                          "baseline/AdaBN, batch-statistics BN" if baseline else arch + " + SAC"),
+            "steps": steps, "warmup": warmup}
+
+
 # ----------------------------------------------------------------------------------------------------------------
 def self_launch(args, json_fd):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks ourselves, one per GPU, free-port
@@ -170,6 +290,7 @@ def main():
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle sample (and with it parity_fullres)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second, event-instrumented pass")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short cfg-2 / cfg-5 runs appended to the N = 1 line")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the instrumented pass (kernels / roofline)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="arithmetic of the forward/data-gradient GEMMs: exact fp32 MFMA (default, the reference's arithmetic) or the "
@@ -308,12 +429,12 @@ def main():
     if not baseline and wrapper != "ddp" and not args.no_kernel_table:
         schedule["fuse"] = not schedule["fuse"]
         try:
-            dt3, _, _ = measure(done, 1, psteps, False)
-            other_sched = round(dt3 / psteps * 1e3, 3)
+            dt3, _, _ = measure(done, 1, args.steps, False)
+            other_sched = round(dt3 / args.steps * 1e3, 3)
         except Exception as exc:
             other_sched = repr(exc)[:200]
         schedule["fuse"] = not schedule["fuse"]
-        done += 1 + psteps
+        done += 1 + args.steps
     fused_now = bool(schedule["fuse"]) and not baseline and wrapper != "ddp" and \
         net.backbone._batch_fits(args.batch + args.groups * args.views, hw[0], hw[1])     # else the driver runs the two passes
     alt = None
@@ -379,6 +500,10 @@ def main():
                          "measured_in": "second pass of {} steps with a HIP event pair around each launch (not the headline's timed region)".format(psteps)},
             "ms_per_step_instrumented": None if dt_prof is None else round(dt_prof / psteps * 1e3, 3),
             "ms_per_step_other_schedule": {("two_pass" if fused_now else "fused"): other_sched},
+            # the module API exactly as train.py calls it -- net(image, masks) then net(frames1, ..., use_teacher=True), two
+            # backward passes (train.py:128,219-222) -- over the same number of steps as `value` (which is the fused schedule)
+            "value_train_py_api": (round(world * args.batch / other_sched * 1e3, 4) if isinstance(other_sched, float) else None)
+            if fused_now else round(world * args.batch * args.steps / dt, 4),
             "kernels": kernel_table(prof, psteps),
             "check": {"loss_ce": losses.get("loss_ce"), "self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"),
                       "labelled_frac": round(labelled, 4)},
@@ -400,6 +525,21 @@ def main():
                     line["parity_fullres"] = parity_fullres(args.size, dev, sample, fuse=fused_now)[1]
                 except Exception as exc:
                     line["parity_fullres"] = {"error": repr(exc)[:200]}
+            del sample
+            torch.cuda.empty_cache()
+            try:      # the multi-view head at full resolution with 8 crops / 4 views per group (head only: seconds of oracle time)
+                hdt, hcmp = head_parity_fullres(args.size, args.groups, args.views, dev)
+                line["parity_fullres_head"] = dict(hcmp, oracle_seconds=round(hdt, 1))
+            except Exception as exc:
+                line["parity_fullres_head"] = {"error": repr(exc)[:200]}
+            if not args.no_other_configs:
+                line["other_configs"] = {}
+                for name in ("cfg2", "cfg5"):
+                    torch.cuda.empty_cache()
+                    try:
+                        line["other_configs"][name] = time_other_config(name, dev)
+                    except Exception as exc:
+                        line["other_configs"][name] = {"error": repr(exc)[:200]}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or force_ddp:
         dist.destroy_process_group()

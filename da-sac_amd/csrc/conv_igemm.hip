@@ -1016,12 +1016,14 @@ __device__ __forceinline__ float sum_splits(const float* __restrict__ p, size_t 
   return (g0 + g1) + (g2 + g3);
 }
 
-// dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[co] += sum W*G (unscaled G);  sum_dz[co] = sum_s Psum[s][co]
+// dW[co][ci][tap] = scale[co] * sum_s P[s][co][(tap0+tap)*Cin+ci];  dot[row][co] = this block's part of sum W*G (unscaled G);
+// sum_dz[co] = sum_s Psum[s][co]
 // grid (chunks of 64 input channels, output channels), 256 threads = 64 channels x 4 split lanes.  A thread adds the splits
 // s = lane, lane + 4, ... of up to 9 taps of ITS channel (9 independent, coalesced slab loads in flight per step); the four
 // lanes meet in LDS and the block writes its 64 x taps gradients in dW's own order -- one contiguous run per block, where the
-// tap-major slab order would touch every 36-byte [ci] group of a 3x3 layer nine times from nine places.  The dot term is
-// combined with one float atomic per block.
+// tap-major slab order would touch every 36-byte [ci] group of a 3x3 layer nine times from nine places.  The dot term
+// leaves as one PARTIAL per block, dot[blockIdx.x][co] (dasac_conv_wgrad_dot_rows rows): bn_param_grads adds the rows in a fixed
+// order, so the gamma gradient is bit-identical from run to run (rounds 1-3 combined them with float atomics).
 constexpr int kWrTaps = 9;
 __global__ __launch_bounds__(256) void wgrad_reduce_scalar(const float* __restrict__ P, const float* __restrict__ Psum, int splits,
                                                     int Mpad, int Kpad, const float* __restrict__ Wt,
@@ -1081,7 +1083,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_scalar(const float* __restri
     part = wave_sum(part);
     if (c == 0) redd[q] = part;
     __syncthreads();
-    if (tx == 0) atomicAdd(&dot[co], (redd[0] + redd[1]) + (redd[2] + redd[3]));
+    if (tx == 0) dot[(size_t)blockIdx.x * gridDim.y + co] = (redd[0] + redd[1]) + (redd[2] + redd[3]);   // partial row: no atomics
   }
 }
 
@@ -1147,7 +1149,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P,
     part = wave_sum(part);
     if (lane == 0) redd[wave] = part;
     __syncthreads();
-    if (tx == 0) atomicAdd(&dot[co], (redd[0] + redd[1]) + (redd[2] + redd[3]));
+    if (tx == 0) dot[(size_t)blockIdx.x * gridDim.y + co] = (redd[0] + redd[1]) + (redd[2] + redd[3]);   // partial row: no atomics
   }
 }
 
@@ -1532,10 +1534,13 @@ extern "C" int dasac_conv_wgrad_x3(const float* dz, const float* x, const int32_
   return conv_wgrad_impl(true, dz, x, table, Nb, Cx, H, W, OH, OW, stride, M, K, workspace, ws_bytes, stream);
 }
 
+extern "C" int dasac_conv_wgrad_dot_rows(int Cin, int taps) { return Cin < 32 ? (Cin * taps + 63) / 64 : (Cin + 63) / 64; }
+
 extern "C" int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K, const float* w,
                                        const float* scale, float* dw, float* dot, float* sum_dz, int Cin, int taps,
                                        int tap0, dasac_stream_t stream) {
   DASAC_REQUIRE(workspace && w && dw, "conv_wgrad_finish: null pointer");
+  DASAC_REQUIRE(!dot || (tap0 == 0 && Cin * taps == K), "conv_wgrad_finish: the dot term is defined for single-branch convolutions");
   const int Mpad = dasac_conv_mpad(M), Kpad = dasac_conv_kpad(K);
   const int bm = pick_bm(Mpad);
   const int splits = wgrad_splits(Mpad, Kpad, Nb * OH * OW, bm, (M % 8 == 0 && bm != 32) ? wgrad_bn(Cin) : 128);

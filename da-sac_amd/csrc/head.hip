@@ -17,6 +17,8 @@ namespace dasac {
 
 constexpr int kMaxC = 32;   // classes held in registers
 constexpr int kHB = 256;
+constexpr float kQ32 = 4294967296.f;     // fixed-point scales of the order-independent (integer) reductions
+constexpr float kQ28 = 268435456.f;
 
 // ---- bilinear taps, align_corners=True (ATen upsample_bilinear2d: src = scale*dst) ----------
 struct Tap {
@@ -38,7 +40,8 @@ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
 // Four consecutive high-res pixels of one row per thread, loop over classes.  Optional outputs:
 //   up    [B,C,H,W]  upsampled logits
 //   probs [B,C,H,W]  softmax(up) * (ignore ? 0 : 1)
-//   csum  [C] double class sums of the UNMASKED softmax (running class prior, sac.py:108)
+//   csum  [C] class sums of the UNMASKED softmax (running class prior, sac.py:108), accumulated in Q32 fixed point
+//         (order-independent => run-to-run bit-identical); the launcher converts the slots to double afterwards
 // CT = compile-time class count (19 for Cityscapes) so the per-pixel class vectors stay in registers.
 // HBM-bound: 76 B written per pixel and output.  Four pixels per thread make every store a (4-byte aligned) dwordx4 and
 // let the pixels share their low-resolution taps: at the 8x factor of the backbone the four x positions touch at most
@@ -49,12 +52,12 @@ template <int CT, bool SOFTMAX>
 __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict__ x, int Crt, int h, int w, int H, int W,
                                                         float sh, float sw, const uint8_t* __restrict__ ignore,
                                                         float* __restrict__ up, float* __restrict__ probs,
-                                                        double* __restrict__ csum, int64_t items) {
+                                                        unsigned long long* __restrict__ csum, int64_t items) {
   const int C = CT < kMaxC ? CT : Crt;          // CT == kMaxC is the generic (runtime-C) instantiation
   const int HW = H * W, hw = h * w, Wq = (W + 3) >> 2;
-  __shared__ float s_sum[kMaxC];
+  __shared__ unsigned long long s_sum[kMaxC];
   if (csum) {
-    if (threadIdx.x < kMaxC) s_sum[threadIdx.x] = 0.f;
+    if (threadIdx.x < kMaxC) s_sum[threadIdx.x] = 0ull;
     __syncthreads();
   }
   float acc[CT];
@@ -173,16 +176,26 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
     }
   }
   if (csum) {
-    // per-thread partials -> wave sums (shuffles) -> one LDS atomic per wave and class -> one double atomic per block
+    // per-thread partials -> wave sums (shuffles, fixed order) -> Q32 fixed point: integer adds commute, so the LDS atomic per
+    // wave and class and the global one per block and class give the SAME bits whatever order the waves / blocks arrive in
+    // (a wave's sum of probabilities is < 2^13, the total < B*HW < 2^31: no overflow; 2^-33 rounding per wave partial).
 #pragma unroll
     for (int c = 0; c < CT; ++c)
       if (c < C) {
         const float ws = wave_sum(acc[c]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum[c], ws);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum[c], __float2ull_rn(ws * kQ32));
       }
     __syncthreads();
-    if (threadIdx.x < C) atomicAdd(&csum[threadIdx.x], (double)s_sum[threadIdx.x]);
+    if (threadIdx.x < C) atomicAdd(&csum[threadIdx.x], s_sum[threadIdx.x]);
   }
+}
+
+// class sums: Q32 fixed point -> double, in place (the caller's buffer holds 8-byte slots either way)
+__global__ void q32_to_double(unsigned long long* __restrict__ q, int C) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const unsigned long long v = q[c];
+  reinterpret_cast<double*>(q)[c] = (double)v * (1.0 / 4294967296.0);
 }
 
 // ---- inference (infer_val.py:160-163 + the writer's argmax / trainId->labelId LUT, :60-65): bilinear(ac=True) +
@@ -298,19 +311,19 @@ __global__ __launch_bounds__(kHB) void upsample_bwd_y(const float* __restrict__ 
 //   mode 0  plain mean (deeplabv2.py:224, sac.py:132):  pw = 1/(B*HW)
 //   mode 1  focal_ce_conf (sac.py:148):                 pw = sum_i conf_i(hw) / (B*B*HW)
 // ce_b = -cw[y]*log_softmax(x)[y], 0 where y == 255.  dlogits (optional) = pw * cw[y] * (softmax - onehot).
-// per_class (optional, [C] double): sum over pixels of ce scattered by label (ignored -> class 0, value 0).
+// per_class (optional, [C] Q28 fixed-point accumulators): sum over pixels of ce scattered by label (ignored pixels add nothing).
 // Four consecutive pixels per thread (the [B,C,HW] layout is contiguous in the flattened pixel index): every class plane
 // is one 4-byte-aligned dwordx4 load and all CT of an image are in flight together.
 template <int CT>
 __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, const int64_t* __restrict__ y,
                                                const float* __restrict__ cw, const float* __restrict__ conf, int B, int Crt,
                                                int HW, int mode, const float* __restrict__ gscale, float* __restrict__ dx,
-                                               double* __restrict__ partial, double* __restrict__ per_class) {
+                                               double* __restrict__ partial, unsigned long long* __restrict__ per_class) {
   const int C = CT < kMaxC ? CT : Crt;
   double lsum = 0.0;
-  __shared__ float s_pc[kMaxC];
+  __shared__ unsigned long long s_pc[kMaxC];
   if (per_class) {
-    if (threadIdx.x < kMaxC) s_pc[threadIdx.x] = 0.f;
+    if (threadIdx.x < kMaxC) s_pc[threadIdx.x] = 0ull;
     __syncthreads();
   }
   const float gs = gscale ? gscale[0] : 1.f;   // upstream gradient of the scalar loss (device side)
@@ -382,7 +395,10 @@ __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, cons
         const float wgt = valid ? (cw ? cw[lab[e]] : 1.f) : 0.f;
         const float ce = valid ? wgt * (logf(den[e]) - (xl[e] - mx[e])) : 0.f;
         cesum[e] += ce;
-        if (per_class && valid && ce != 0.f && e < nx) atomicAdd(&s_pc[lab[e]], ce);
+        // Q28 two's-complement fixed point: integer adds commute, so the scatter is bit-identical from run to run
+        // (exact for ce >= 2^-4, 2^-29 rounding below; |ce| clamped to 4096: N*4096*2^28 < 2^63 for N < 2^23 pixels)
+        if (per_class && valid && ce != 0.f && e < nx)
+          atomicAdd(&s_pc[lab[e]], (unsigned long long)__float2ll_rn(fminf(fmaxf(ce, -4096.f), 4096.f) * kQ28));
         gw[e] = pw[e] * gs * wgt;
         k[e] = gw[e] / den[e];
       }
@@ -413,16 +429,17 @@ __global__ __launch_bounds__(kHB) void ce_loss(const float* __restrict__ x, cons
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-  if (per_class && threadIdx.x < C && s_pc[threadIdx.x] != 0.f) atomicAdd(&per_class[threadIdx.x], (double)s_pc[threadIdx.x]);
+  if (per_class && threadIdx.x < C && s_pc[threadIdx.x] != 0ull) atomicAdd(&per_class[threadIdx.x], s_pc[threadIdx.x]);
 }
 
 __global__ void ce_finish(const double* __restrict__ partial, int n, float* __restrict__ loss,
-                          double* __restrict__ per_class, float* __restrict__ per_class_out, int C, double pc_norm) {
+                          const unsigned long long* __restrict__ per_class, float* __restrict__ per_class_out, int C, double pc_norm) {
   double s = 0;
   for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
   s = wave_sum(s);
   if (threadIdx.x == 0) loss[0] = (float)s;
-  if (per_class_out && threadIdx.x < C) per_class_out[threadIdx.x] = (float)(per_class[threadIdx.x] * pc_norm);
+  if (per_class_out && threadIdx.x < C)
+    per_class_out[threadIdx.x] = (float)((double)(long long)per_class[threadIdx.x] * (1.0 / 268435456.0) * pc_norm);
 }
 
 // ---- cross-entropy backward straight into the low-resolution gradient (K15 -> K9^T) ------------------------------
@@ -757,7 +774,7 @@ extern "C" int dasac_upsample_softmax(const float* logits, int B, int C, int h, 
   const int grid = stream_grid(items, kHB, softmax ? kNumCu * 4 : kNumCu * 16);
 #define DASAC_UPS(CT, SM)                                                                                              \
   hipLaunchKernelGGL((upsample_softmax<CT, SM>), dim3(grid), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), \
-                     ac_scale(w, W), ignore, up, probs, class_sums, items)
+                     ac_scale(w, W), ignore, up, probs, reinterpret_cast<unsigned long long*>(class_sums), items)
   if (C == 19) {
     if (softmax) DASAC_UPS(19, true); else DASAC_UPS(19, false);
   } else {
@@ -765,6 +782,10 @@ extern "C" int dasac_upsample_softmax(const float* logits, int B, int C, int h, 
   }
 #undef DASAC_UPS
   DASAC_CHECK_LAUNCH("upsample_softmax");
+  if (class_sums) {
+    hipLaunchKernelGGL(q32_to_double, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(class_sums), C);
+    DASAC_CHECK_LAUNCH("q32_to_double");
+  }
   return DASAC_OK;
 }
 
@@ -815,7 +836,8 @@ extern "C" int dasac_ce_loss(const float* logits, const int64_t* labels, const f
   hipStream_t s = as_stream(stream);
   const int blocks = ce_blocks(HW);
   double* partial = reinterpret_cast<double*>(workspace);
-  double* pc = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)blocks * sizeof(double), 256));
+  unsigned long long* pc =
+      reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + align_up((size_t)blocks * sizeof(double), 256));
   if (per_class) DASAC_HIP(hipMemsetAsync(pc, 0, kMaxC * sizeof(double), s));
   if (C == 19)
     hipLaunchKernelGGL(ce_loss<19>, dim3(blocks), dim3(kHB), 0, s, logits, labels, class_weight, conf, B, C, (int)HW, mode, gscale,

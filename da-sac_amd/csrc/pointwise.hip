@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void bn_fold_multi(const dasac_fold_job* __res
 }
 
 // dgamma = invstd*(dot + (b - mean)*sum_dz), dbeta = sum_dz, dbias_conv = scale*sum_dz
-__global__ void bn_param_grads(const float* __restrict__ dot, const float* __restrict__ sum_dz, const float* __restrict__ mean,
+// dot: [dot_rows][C] partial rows of dasac_conv_wgrad_finish, added here in row order (deterministic)
+__global__ void bn_param_grads(const float* __restrict__ dot, int dot_rows, const float* __restrict__ sum_dz,
+                               const float* __restrict__ mean,
                                const float* __restrict__ invstd, const float* __restrict__ scale,
                                const float* __restrict__ conv_bias, int C, float* __restrict__ dgamma,
                                float* __restrict__ dbeta, float* __restrict__ dbias) {
@@ -42,7 +44,11 @@ __global__ void bn_param_grads(const float* __restrict__ dot, const float* __res
   if (c >= C) return;
   const float s = sum_dz[c];
   const float b = conv_bias ? conv_bias[c] : 0.f;
-  if (dgamma) dgamma[c] = invstd[c] * (dot[c] + (b - mean[c]) * s);
+  if (dgamma) {
+    float d = 0.f;
+    for (int r = 0; r < dot_rows; ++r) d += dot[(size_t)r * C + c];
+    dgamma[c] = invstd[c] * (d + (b - mean[c]) * s);
+  }
   if (dbeta) dbeta[c] = s;
   if (dbias) dbias[c] = (scale ? scale[c] : 1.f) * s;
 }
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy,
 }
 
 // ---- momentum teacher (models/sac.py:83-102) as one multi-tensor launch --------------------------
-// chunk table: for chunk i, tensor id + element offset.  sq[tensor] += sum (slow-fast)^2 (pre-update);
+// chunk table: for chunk i, tensor id + chunk index.  sq_chunk[i] = sum (slow-fast)^2 over the chunk (pre-update);
 // if update: slow = slow*m + fast*(1-m).
 struct TensorPair {
   const float* fast;
@@ -194,7 +200,7 @@ struct TensorPair {
 constexpr int kEmaChunk = 256 * 16;
 
 __global__ __launch_bounds__(256) void ema_chunks(const TensorPair* __restrict__ pairs, const int2* __restrict__ chunks,
-                                                  float momentum, float one_minus, int update, double* __restrict__ sq) {
+                                                  float momentum, float one_minus, int update, double* __restrict__ sq_chunk) {
   const int2 ch = chunks[blockIdx.x];
   const TensorPair tp = pairs[ch.x];
   const int64_t base = (int64_t)ch.y * kEmaChunk;
@@ -217,7 +223,22 @@ __global__ __launch_bounds__(256) void ema_chunks(const TensorPair* __restrict__
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&sq[ch.x], red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) sq_chunk[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);      // one partial per chunk: no atomics
+}
+
+// sq[t] = sum of tensor t's chunk partials, in a fixed order (one wave per tensor; `chunks` is sorted by tensor id)
+__global__ __launch_bounds__(64) void ema_tensor_sums(const int2* __restrict__ chunks, int n_chunks, const double* __restrict__ sq_chunk,
+                                                      double* __restrict__ sq) {
+  const int t = blockIdx.x;
+  int lo = 0, hi = n_chunks;                       // first chunk whose tensor id is >= t
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (chunks[mid].x < t) lo = mid + 1; else hi = mid;
+  }
+  double s = 0;
+  for (int i = lo + threadIdx.x; i < n_chunks && chunks[i].x == t; i += 64) s += sq_chunk[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) sq[t] = s;
 }
 
 __global__ void ema_finish(const double* __restrict__ sq, int n, float* __restrict__ out) {
@@ -309,11 +330,11 @@ extern "C" int dasac_bn_fold_multi(const dasac_fold_job* jobs, const int32_t* ch
   return DASAC_OK;
 }
 
-extern "C" int dasac_bn_param_grads(const float* dot, const float* sum_dz, const float* mean, const float* invstd,
+extern "C" int dasac_bn_param_grads(const float* dot, int dot_rows, const float* sum_dz, const float* mean, const float* invstd,
                                     const float* scale, const float* conv_bias, int C, float* dgamma, float* dbeta,
                                     float* dbias, dasac_stream_t stream) {
-  DASAC_REQUIRE(sum_dz && C > 0 && (!dgamma || (dot && mean && invstd)), "bn_param_grads: bad arguments");
-  hipLaunchKernelGGL(bn_param_grads, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), dot, sum_dz, mean, invstd, scale,
+  DASAC_REQUIRE(sum_dz && C > 0 && (!dgamma || (dot && dot_rows > 0 && mean && invstd)), "bn_param_grads: bad arguments");
+  hipLaunchKernelGGL(bn_param_grads, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), dot, dot_rows, sum_dz, mean, invstd, scale,
                      conv_bias, C, dgamma, dbeta, dbias);
   DASAC_CHECK_LAUNCH("bn_param_grads");
   return DASAC_OK;
@@ -359,17 +380,20 @@ extern "C" int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t*
 extern "C" int dasac_ema_chunk_elems(void) { return kEmaChunk; }
 
 // pairs: device array of {fast*, slow*, int64 n} (24 bytes each); chunks: device array of int32 pairs
-// (tensor id, chunk index within the tensor); sq: device [n_tensors] doubles (scratch); out: device [1].
+// (tensor id, chunk index within the tensor), SORTED by tensor id; sq: device [n_tensors + n_chunks] doubles (scratch: per-tensor
+// sums, then one partial per chunk -- summed in a fixed order, so teacher_diff is bit-identical from run to run); out: device [1].
 extern "C" int dasac_ema_update(const void* pairs, int n_tensors, const int32_t* chunks, int n_chunks, float momentum,
                                 int update, double* sq, float* out, dasac_stream_t stream) {
   DASAC_REQUIRE(pairs && chunks && sq && out && n_tensors > 0 && n_chunks > 0, "ema_update: bad arguments");
   hipStream_t s = as_stream(stream);
-  DASAC_HIP(hipMemsetAsync(sq, 0, (size_t)n_tensors * sizeof(double), s));
+  double* sq_chunk = sq + n_tensors;
   // sac.py:95 multiplies by the python double (1. - momentum) cast to fp32
   const float one_minus = (float)(1.0 - (double)momentum);
   hipLaunchKernelGGL(ema_chunks, dim3(n_chunks), dim3(256), 0, s, reinterpret_cast<const TensorPair*>(pairs),
-                     reinterpret_cast<const int2*>(chunks), momentum, one_minus, update, sq);
+                     reinterpret_cast<const int2*>(chunks), momentum, one_minus, update, sq_chunk);
   DASAC_CHECK_LAUNCH("ema_chunks");
+  hipLaunchKernelGGL(ema_tensor_sums, dim3(n_tensors), dim3(64), 0, s, reinterpret_cast<const int2*>(chunks), n_chunks, sq_chunk, sq);
+  DASAC_CHECK_LAUNCH("ema_tensor_sums");
   hipLaunchKernelGGL(ema_finish, dim3(1), dim3(64), 0, s, sq, n_tensors, out);
   DASAC_CHECK_LAUNCH("ema_finish");
   return DASAC_OK;
@@ -423,9 +447,11 @@ namespace dasac {
 
 constexpr int kBnChunk = 256 * 16;
 
-// sums[c] += sum z, sums[C + c] += sum z^2   (double atomics, grid = (chunks, N*C planes))
-__global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int C, int HW, double* __restrict__ sums) {
-  const int plane = blockIdx.y, c = plane % C;
+// Two-stage, atomic-free (deterministic) per-channel reductions: stage 1 writes one (s, q) pair of doubles per (plane, chunk),
+// stage 2 (bn_sums_finish, one wave per channel) adds the N*chunks pairs of a channel in a fixed order.
+// partial[(plane*chunks + chunk)*2 + {0,1}] = sum z, sum z^2 of the chunk        (grid = (chunks, N*C planes))
+__global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int C, int HW, double* __restrict__ partial) {
+  const int plane = blockIdx.y;
   const float* p = z + (size_t)plane * HW;
   double s = 0, q = 0;
   for (int i = blockIdx.x * kBnChunk + threadIdx.x; i < min(HW, (int)(blockIdx.x + 1) * kBnChunk); i += 256) {
@@ -442,8 +468,28 @@ __global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[c], rs[0] + rs[1] + rs[2] + rs[3]);
-    atomicAdd(&sums[C + c], rq[0] + rq[1] + rq[2] + rq[3]);
+    double* o = partial + ((size_t)plane * gridDim.x + blockIdx.x) * 2;
+    o[0] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    o[1] = (rq[0] + rq[1]) + (rq[2] + rq[3]);
+  }
+}
+
+// sums[c] = sum over (n, chunk) of the s-partials, sums[C + c] = of the q-partials; grid C, one wave each
+__global__ __launch_bounds__(64) void bn_sums_finish(const double* __restrict__ partial, int N, int C, int chunks,
+                                                     double* __restrict__ sums) {
+  const int c = blockIdx.x;
+  double s = 0, q = 0;
+  for (int j = threadIdx.x; j < N * chunks; j += 64) {
+    const int n = j / chunks, k = j - n * chunks;
+    const double* o = partial + ((size_t)(n * C + c) * chunks + k) * 2;
+    s += o[0];
+    q += o[1];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (threadIdx.x == 0) {
+    sums[c] = s;
+    sums[C + c] = q;
   }
 }
 
@@ -489,10 +535,10 @@ __global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ z, con
   }
 }
 
-// sums[c] += sum dy, sums[C + c] += sum dy * xhat,  xhat = (z - mean)*invstd
+// partial pairs (as bn_stats) of sum dy, sum dy * xhat,  xhat = (z - mean)*invstd
 __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd, int C,
-                                                     int HW, double* __restrict__ sums) {
+                                                     int HW, double* __restrict__ partial) {
   const int plane = blockIdx.y, c = plane % C;
   const float* pd = dy + (size_t)plane * HW;
   const float* pz = z + (size_t)plane * HW;
@@ -512,8 +558,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ d
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[c], rs[0] + rs[1] + rs[2] + rs[3]);
-    atomicAdd(&sums[C + c], rq[0] + rq[1] + rq[2] + rq[3]);
+    double* o = partial + ((size_t)plane * gridDim.x + blockIdx.x) * 2;
+    o[0] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    o[1] = (rq[0] + rq[1]) + (rq[2] + rq[3]);
   }
 }
 
@@ -542,12 +589,21 @@ __global__ void bn_bwd_params(const double* __restrict__ sums, int C, float* __r
 
 }  // namespace dasac
 
-extern "C" int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, dasac_stream_t stream) {
-  DASAC_REQUIRE(z && sums && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31), "bn_stats: bad arguments");
+extern "C" size_t dasac_bn_stats_workspace(int N, int C, int64_t HW) {
+  return (size_t)N * C * (size_t)((HW + kBnChunk - 1) / kBnChunk) * 2 * sizeof(double);
+}
+
+extern "C" int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, void* workspace, size_t ws_bytes,
+                              dasac_stream_t stream) {
+  DASAC_REQUIRE(z && sums && workspace && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31), "bn_stats: bad arguments");
+  if (ws_bytes < dasac_bn_stats_workspace(N, C, HW)) return fail(DASAC_EWORKSPACE, "bn_stats: workspace too small");
   hipStream_t s = as_stream(stream);
-  DASAC_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), s));
-  hipLaunchKernelGGL(bn_stats, dim3((unsigned)((HW + kBnChunk - 1) / kBnChunk), N * C), dim3(256), 0, s, z, C, (int)HW, sums);
+  const int chunks = (int)((HW + kBnChunk - 1) / kBnChunk);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(bn_stats, dim3((unsigned)chunks, N * C), dim3(256), 0, s, z, C, (int)HW, partial);
   DASAC_CHECK_LAUNCH("bn_stats");
+  hipLaunchKernelGGL(bn_sums_finish, dim3(C), dim3(64), 0, s, partial, N, C, chunks, sums);
+  DASAC_CHECK_LAUNCH("bn_sums_finish");
   return DASAC_OK;
 }
 
@@ -574,13 +630,17 @@ extern "C" int dasac_bn_apply(const float* z, const float* scale, const float* s
 }
 
 extern "C" int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd, int N, int C,
-                                   int64_t HW, double* sums, dasac_stream_t stream) {
-  DASAC_REQUIRE(dy && z && mean && invstd && sums && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31), "bn_bwd_reduce: bad arguments");
+                                   int64_t HW, double* sums, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+  DASAC_REQUIRE(dy && z && mean && invstd && sums && workspace && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31),
+                "bn_bwd_reduce: bad arguments");
+  if (ws_bytes < dasac_bn_stats_workspace(N, C, HW)) return fail(DASAC_EWORKSPACE, "bn_bwd_reduce: workspace too small");
   hipStream_t s = as_stream(stream);
-  DASAC_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(double), s));
-  hipLaunchKernelGGL(bn_bwd_reduce, dim3((unsigned)((HW + kBnChunk - 1) / kBnChunk), N * C), dim3(256), 0, s, dy, z, mean, invstd,
-                     C, (int)HW, sums);
+  const int chunks = (int)((HW + kBnChunk - 1) / kBnChunk);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(bn_bwd_reduce, dim3((unsigned)chunks, N * C), dim3(256), 0, s, dy, z, mean, invstd, C, (int)HW, partial);
   DASAC_CHECK_LAUNCH("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_sums_finish, dim3(C), dim3(64), 0, s, partial, N, C, chunks, sums);
+  DASAC_CHECK_LAUNCH("bn_sums_finish");
   return DASAC_OK;
 }
 

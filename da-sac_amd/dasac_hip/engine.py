@@ -464,10 +464,11 @@ class Engine:
             return torch.empty(cout, dtype=torch.float32, device=device) if out is None else out.view(cout)
 
         g = {self.plan.output: grad_out.contiguous()}
-        # the d-gamma dot terms of all frozen-BN convs accumulate into slices of ONE zero-filled vector (one fill kernel
-        # per backward pass instead of one per layer)
+        # the d-gamma dot terms of all frozen-BN convs are slices of ONE vector: [dot_rows, cout] partial rows per layer, every
+        # element written by the weight-gradient finish and added in a fixed order by bn_param_grads (no atomics, no fill)
         dot_pool, dot_used = None, 0
-        dot_total = sum(op.spec.cout for op in self.plan.ops if op.kind == "conv" and op.bn is not None and op.expanded is None)
+        dot_total = sum(ops.dot_rows(op.spec) * op.spec.cout for op in self.plan.ops
+                        if op.kind == "conv" and op.bn is not None and op.expanded is None)
         pending = list(self.consumers)
         pending[self.plan.output] = 0
 
@@ -545,9 +546,10 @@ class Engine:
                 if any(w_need) or want_bn:
                     if want_bn:
                         if dot_pool is None:
-                            dot_pool = torch.zeros(dot_total, dtype=torch.float32, device=dz.device)
-                        dot = dot_pool[dot_used:dot_used + spec.cout]
-                        dot_used += spec.cout
+                            dot_pool = torch.empty(dot_total, dtype=torch.float32, device=dz.device)
+                        rows = ops.dot_rows(spec)
+                        dot = dot_pool[dot_used:dot_used + rows * spec.cout].view(rows, spec.cout)
+                        dot_used += rows * spec.cout
                     if want_bn or want_bias:      # channel sums ride along with the wgrad kernel
                         sums = sums_dest(b_idx, want_bias and (train_bn or op.bn is None), spec.cout, dz.device)
                     dws = ops.conv_wgrad(spec, dz, xin, [c.weight.detach() for c in op.convs], scale=scale, dot=dot,

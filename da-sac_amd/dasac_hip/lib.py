@@ -44,7 +44,7 @@ PROTOTYPES = {
     "dasac_warp_back": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_class_state": (_i, [_p, _p, _i, _l, _i, _f, _f, _i, _f, _p, _p, _p]),
     "dasac_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p]),
-    "dasac_bn_param_grads": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "dasac_bn_param_grads": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "dasac_channel_sums": (_i, [_p, _i, _i, _l, _p, _p]),
     "dasac_maxpool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dasac_maxpool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
@@ -54,10 +54,11 @@ PROTOTYPES = {
     "dasac_scale_planes": (_i, [_p, _p, _l, _l, _p, _p]),
     "dasac_add": (_i, [_p, _p, _p, _l, _p]),
     "dasac_relu_mask": (_i, [_p, _p, _p, _l, _p]),
-    "dasac_bn_stats": (_i, [_p, _i, _i, _l, _p, _p]),
+    "dasac_bn_stats_workspace": (_sz, [_i, _i, _l]),
+    "dasac_bn_stats": (_i, [_p, _i, _i, _l, _p, _p, _sz, _p]),
     "dasac_bn_train_finalize": (_i, [_p, C.c_double, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
     "dasac_bn_apply": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p, _p]),
-    "dasac_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p]),
+    "dasac_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p, _sz, _p]),
     "dasac_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, C.c_double, _p, _i, _i, _l, _p, _p, _p, _p]),
     "dasac_conv_pack_expanded": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dasac_tap_gather": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
@@ -73,6 +74,7 @@ PROTOTYPES = {
     "dasac_make_views": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "dasac_view_photometric_workspace": (_sz, [_i, _i, _i]),
     "dasac_view_photometric": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _sz, _p]),
+    "dasac_conv_wgrad_dot_rows": (_i, [_i, _i]),
     "dasac_conv_wgrad_finish": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 
@@ -112,10 +114,39 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_checked_devices = {}
+EXPECTED_CUS, EXPECTED_ARCH = 256, "gfx950"       # csrc/common.hpp: kNumCu / kNumXcd = 256 / 8 size every grid and tile run
+
+
+def check_device(index):
+    """Fails loudly when the device is not what the kernels were tuned and compiled for: a full MI355X (gfx950, 64-wide
+    waves, 256 CUs in 8 XCDs).  A partitioned (CPX / fewer-CU) device would run with mistuned grids and a refused stream-K
+    schedule; DASAC_ALLOW_OTHER_DEVICE=1 turns the error into a warning for experiments."""
+    if index in _checked_devices:
+        return _checked_devices[index]
+    lib = load()
+    cus, wave, arch = _i(0), _i(0), C.create_string_buffer(64)
+    with torch.cuda.device(index):
+        check(lib.dasac_device_info(C.byref(cus), C.byref(wave), arch, 64), "dasac_device_info")
+    info = (cus.value, wave.value, arch.value.decode().split(":")[0])
+    if info != (EXPECTED_CUS, 64, EXPECTED_ARCH):
+        msg = "libdasac_hip.so is built and tuned for {} with {} CUs and 64-wide waves; cuda:{} reports {} with {} CUs, wave {}".format(
+            EXPECTED_ARCH, EXPECTED_CUS, index, info[2], info[0], info[1])
+        if os.environ.get("DASAC_ALLOW_OTHER_DEVICE", "0") != "1":
+            raise DasacError(msg + " (set DASAC_ALLOW_OTHER_DEVICE=1 to run anyway)")
+        import warnings
+        warnings.warn(msg)
+    _checked_devices[index] = info
+    return info
+
+
 def require_gpu(*tensors):
     for t in tensors:
-        if t is not None and not t.is_cuda:
-            raise DasacError("dasac_hip ops run on the MI355X only (got a {} tensor); no CPU fallback".format(t.device))
+        if t is not None:
+            if not t.is_cuda:
+                raise DasacError("dasac_hip ops run on the MI355X only (got a {} tensor); no CPU fallback".format(t.device))
+            if t.device.index not in _checked_devices:
+                check_device(t.device.index)
 
 
 _ws_cache = {}

@@ -262,12 +262,19 @@ def conv_dgrad(spec, dz, weights, in_hw, scale=None, res=None, mask=None, table=
     return relu_mask(dx, mask) if mask is not None else dx
 
 
+def dot_rows(spec):
+    """Rows of the partial d-gamma dot term `conv_wgrad(dot=...)` fills (one per block of 64 input channels)."""
+    return L.load().dasac_conv_wgrad_dot_rows(spec.cin, spec.taps)
+
+
 def conv_wgrad(spec, dz, x, weights, scale=None, dot=None, table=None, sum_dz=None, outs=None):
-    """Returns [dW per branch]; optionally accumulates dot[co] += sum_k W*G (unscaled G) and fills
-    sum_dz[co] = sum over batch and pixels of dz.  `outs`: destination per branch (None entries are allocated) --
-    a gradient sink hands out slices of its flat reduction buffer here."""
+    """Returns [dW per branch]; optionally fills dot [dot_rows(spec), Cout] with the partial rows of sum_k W*G (unscaled G;
+    `bn_param_grads` adds them in a fixed order -- no atomics) and sum_dz[co] = sum over batch and pixels of dz.
+    `outs`: destination per branch (None entries are allocated) -- a gradient sink hands out slices of its flat
+    reduction buffer here."""
     lib = L.load()
     L.require_gpu(dz, x, *weights)
+    assert dot is None or (tuple(dot.shape) == (dot_rows(spec), spec.cout) and dot.is_contiguous())
     Nb, Cx, H, W = x.shape
     _, M, OH, OW = dz.shape
     table = conv_table(spec, H, W, False, x.device) if table is None else table
@@ -556,7 +563,8 @@ def bn_param_grads(dot, sum_dz, mean, invstd, scale, conv_bias, want_gamma=True,
     dg = _dest(outs[0], sum_dz) if want_gamma else None
     db = _dest(outs[1], sum_dz) if want_beta else None
     dcb = _dest(outs[2], sum_dz) if want_bias else None
-    L.check(lib.dasac_bn_param_grads(L.ptr(dot), sum_dz.data_ptr(), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(conv_bias),
+    assert dot is None or (dot.dim() == 2 and dot.shape[1] == Cn and dot.is_contiguous())
+    L.check(lib.dasac_bn_param_grads(L.ptr(dot), 0 if dot is None else dot.shape[0], sum_dz.data_ptr(), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(conv_bias),
                                      Cn, L.ptr(dg), L.ptr(db), L.ptr(dcb), L.stream_ptr()), "dasac_bn_param_grads")
     return dg, db, dcb
 
@@ -650,17 +658,17 @@ def label_pad_mask(labels, pad_label=-1, ignore_label=255):
     return mask
 
 
-_dropout_calls = 0
-
-
 def dropout_planes(B, Cn, p, device):
-    """Dropout2d noise [B, C]: keep/(1-p), drawn on the device (Philox keyed by torch's CUDA seed, one offset per call)."""
-    global _dropout_calls
+    """Dropout2d noise [B, C]: keep/(1-p), drawn on the device by a counter-based Philox keyed on torch's CUDA generator.
+    (seed, offset) come from the device generator's own Philox state and the offset is ADVANCED there, so
+    torch.manual_seed / torch.cuda.get_rng_state / set_rng_state (checkpoint resume) reproduce the masks exactly as they
+    do for ATen's dropout, per device.  (The numbers are not ATen's -- parity tests inject `module.keep_mask`.)"""
     lib = L.load()
     out = torch.empty((B, Cn), dtype=torch.float32, device=device)
-    seed = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()].initial_seed()
-    _dropout_calls += 1
-    L.check(lib.dasac_dropout_planes(seed & 0xFFFFFFFFFFFFFFFF, _dropout_calls, float(p), B * Cn, out.data_ptr(), L.stream_ptr()),
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(offset + 4 * ((B * Cn + 3) // 4))             # Philox offsets move in multiples of 4
+    L.check(lib.dasac_dropout_planes(seed & 0xFFFFFFFFFFFFFFFF, offset, float(p), B * Cn, out.data_ptr(), L.stream_ptr()),
             "dasac_dropout_planes")
     return out
 
@@ -671,9 +679,16 @@ def class_sums(probs):
     L.require_gpu(probs)
     probs = _c(probs)
     B, Cn = probs.shape[0], probs.shape[1]
-    sums = torch.empty(2 * Cn, dtype=torch.float64, device=probs.device)
-    L.check(lib.dasac_bn_stats(probs.data_ptr(), B, Cn, probs[0, 0].numel(), sums.data_ptr(), L.stream_ptr()), "dasac_bn_stats")
-    return sums[:Cn]
+    return _bn_sums(lib.dasac_bn_stats, (probs.data_ptr(),), B, Cn, probs[0, 0].numel(), probs.device, "dasac_bn_stats")[:Cn]
+
+
+def _bn_sums(fn, lead_ptrs, N, Cn, HW, device, what):
+    """Two-stage per-channel reduction (dasac_bn_stats / dasac_bn_bwd_reduce): float64 [2*C]."""
+    lib = L.load()
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=device)
+    ws = L.workspace(lib.dasac_bn_stats_workspace(N, Cn, HW), device)
+    L.check(fn(*lead_ptrs, N, Cn, HW, sums.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()), what)
+    return sums
 
 
 def bump_versions(tensors):
@@ -703,7 +718,7 @@ class EmaPlan:
         self.key = tuple(int(v) for v in pairs[:, :2].reshape(-1))
         self.pairs = torch.from_numpy(pairs).to(dev)
         self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
-        self.sq = torch.empty(len(fast_tensors), dtype=torch.float64, device=dev)
+        self.sq = torch.empty(len(fast_tensors) + len(chunks), dtype=torch.float64, device=dev)   # per-tensor sums + chunk partials
         self.n_tensors, self.n_chunks = len(fast_tensors), len(chunks)
         self.slow = list(slow_tensors)
 
@@ -743,8 +758,7 @@ def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
     L.require_gpu(z, res)
     N, Cn = z.shape[0], z.shape[1]
     HW = z[0, 0].numel()
-    sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
-    L.check(lib.dasac_bn_stats(z.data_ptr(), N, Cn, HW, sums.data_ptr(), L.stream_ptr()), "dasac_bn_stats")
+    sums = _bn_sums(lib.dasac_bn_stats, (z.data_ptr(),), N, Cn, HW, z.device, "dasac_bn_stats")
     sums, count, count_dev = _allreduce_sums(sums, N * HW)
     scale, shift, mean, invstd = (_f32((Cn,), z) for _ in range(4))
     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
@@ -769,9 +783,8 @@ def bn_train_backward(dy, z, stats, gamma, want_params=True, outs=(None, None)):
     N, Cn = z.shape[0], z.shape[1]
     HW = z[0, 0].numel()
     dy = _c(dy)
-    sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
-    L.check(lib.dasac_bn_bwd_reduce(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), N, Cn, HW, sums.data_ptr(),
-                                    L.stream_ptr()), "dasac_bn_bwd_reduce")
+    sums = _bn_sums(lib.dasac_bn_bwd_reduce, (dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr()), N, Cn, HW, z.device,
+                    "dasac_bn_bwd_reduce")
     local = sums
     if _world() > 1:
         import torch.distributed as dist

@@ -50,7 +50,8 @@ class GradSink:
         self.pg = process_group
         self.bucket_bytes = int(bucket_bytes)
         self.reduce_single_rank = bool(reduce_single_rank)
-        self._layout_key, self._offsets, self._shapes, self._bucket_of, self._buckets = None, None, None, None, None
+        self._layout_engine, self._layout_key = None, None
+        self._offsets, self._shapes, self._bucket_of, self._buckets = None, None, None, None
         self._flat, self._pending, self._works, self._scale = None, None, [], {}
         self.launched, self.launched_early = 0, 0   # statistics (tests): reductions issued / issued before the backward ended
 
@@ -83,14 +84,18 @@ class GradSink:
         self._offsets, self._shapes, self._bucket_of, self._buckets, self._total = offsets, shapes, bucket_of, buckets, off
 
     def begin(self, engine, need, grad_out):
-        key = (id(engine), tuple(bool(n) for n in need))
-        if self._layout_key != key:
+        # keyed on the engine OBJECT (held here, compared by identity): BaseNet rebuilds its engine when it is stale and a
+        # freed engine's id() can be handed to the new one -- an id-keyed cache would then reuse offsets of another plan
+        key = tuple(bool(n) for n in need)
+        if self._layout_engine is not engine or self._layout_key != key:
             self._build_layout(engine, need)
-            self._layout_key = key
+            self._layout_engine, self._layout_key = engine, key
         # A FRESH buffer per backward pass: the gradients of an earlier pass (still referenced by .grad or set aside by
         # FusedSGD.stash_grads) keep their own buffer alive; the caching allocator recycles it once they are gone.
         self._flat = torch.empty(max(self._total, 1), dtype=torch.float32, device=grad_out.device)
         self._pending = [len(m) for (_, _, m) in self._buckets]
+        self._written = set()
+        self._launches = [0] * len(self._buckets)
         self._works = []
         self._device = grad_out.device
         world = self.world()
@@ -115,6 +120,7 @@ class GradSink:
 
     def _launch(self, b, early):
         self._pending[b] = -1
+        self._launches[b] += 1
         world = self.world()
         if world == 1 and not self.reduce_single_rank:
             return
@@ -126,8 +132,9 @@ class GradSink:
     def done(self, indices):
         for j in indices:
             b = self._bucket_of.get(j)
-            if b is None or self._pending[b] < 0:
+            if b is None or self._pending[b] < 0 or j in self._written:
                 continue
+            self._written.add(j)
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b, True)
@@ -136,9 +143,13 @@ class GradSink:
         for b, left in enumerate(self._pending):
             if left >= 0:                          # a layer that produced no gradient in this pass: reduce what is there
                 if left > 0:
-                    lo, hi, _ = self._buckets[b]
-                    self._flat[lo:hi].zero_()      # never-written slices must not carry garbage into the sum
+                    # ONLY the slices nobody wrote (their parameters' grads stay None, but the collective reads them) are
+                    # cleared -- the bucket's other members already hold gradients that autograd was handed as views
+                    for j in self._buckets[b][2]:
+                        if j not in self._written:
+                            self.alloc(j).zero_()
                 self._launch(b, False)
+        assert all(n == 1 for n in self._launches), "GradSink: a bucket was reduced {} times in one pass".format(self._launches)
         for w in self._works:
             w.wait()                               # nccl: the CURRENT STREAM waits (no host block); gloo: host wait
         self._works = []
@@ -177,6 +188,7 @@ class OverlappedDataParallel(nn.Module):
             sink = GradSink(process_group, int(bucket_mb) << 20, reduce_single_rank)
             net._grad_sink = sink
             self._sinks.append(sink)
+        self._covered = None                      # checked lazily: the engines are built by the first forward
         ignore = set(getattr(module, "_ddp_params_and_buffers_to_ignore", []))
         self._synced_buffers = [b for n, b in module.named_buffers() if n not in ignore]
         self._sync_module_states()
@@ -209,7 +221,29 @@ class OverlappedDataParallel(nn.Module):
         are exempt from the per-forward broadcast (ranks that loaded different snapshots would otherwise diverge silently)."""
         self._broadcast([p for p in self.module.parameters()] + [b for b in self.module.buffers()])
 
+    def _check_coverage(self):
+        """Every trainable parameter must be reduced by somebody.  Stock DDP reduces whatever requires grad; this wrapper only
+        what the sunk engines differentiate -- a trainable parameter outside their plans (a new head outside BaseNet, a
+        backbone without `_plan`, a `requires_grad` flip after construction) would silently diverge between ranks."""
+        trainable = {id(p): n for n, p in self.module.named_parameters() if p.requires_grad}
+        key = tuple(sorted(trainable))
+        if self._covered == key:
+            return
+        from models.basenet import BaseNet
+        reduced = set()
+        for net in self.module.modules():
+            if isinstance(net, BaseNet) and net._grad_sink is not None:
+                if net._engine is None or net._engine.stale():
+                    return                       # plan not captured yet: checked again at the next forward
+                reduced.update(id(p) for p in net._engine.params)
+        missing = [n for i, n in trainable.items() if i not in reduced]
+        if missing:
+            raise RuntimeError("OverlappedDataParallel: trainable parameters outside every engine plan would never be "
+                               "all-reduced: {} (wrap the model in torch's DistributedDataParallel instead)".format(missing[:4]))
+        self._covered = key
+
     def forward(self, *args, **kwargs):
+        self._check_coverage()
         if self.broadcast_buffers:            # DDP syncs its buffers before EVERY forward (train, eval and no-grad alike)
             self._broadcast(self._synced_buffers)
         return self.module(*args, **kwargs)
@@ -217,6 +251,7 @@ class OverlappedDataParallel(nn.Module):
     def forward_fused(self, *args, **kwargs):
         """`SAC.forward_fused` (both student passes of an iteration as one) under the same buffer synchronisation; the one
         backward pass that follows reduces source + target gradients together."""
+        self._check_coverage()
         if self.broadcast_buffers:
             self._broadcast(self._synced_buffers)
         return self.module.forward_fused(*args, **kwargs)

@@ -365,6 +365,13 @@ def validation_iou(net, batches, num_classes=19):
     core.train(was)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(counts)
-    tp, fp, fn = counts[0].double(), counts[1].double(), counts[2].double()
-    iou = tp / (tp + fp + fn).clamp_min(1.0)
+    iou, _, _ = summarise_iou(counts)
     return float(iou.mean()), iou
+
+
+def summarise_iou(counts):
+    """`Jaccard.summarise` (utils/metrics.py:40-53) on int64 counts [3, C] = (tp, fp, fn): per-class
+    (jaccard, precision, recall) = tp / max(1e-3, .) in float32 like the reference (a class that never occurs scores 0)."""
+    tp, fp, fn = (counts[i].to(torch.float32).cpu() for i in range(3))
+    floor = torch.tensor(1e-3)
+    return tp / torch.maximum(floor, fn + fp + tp), tp / torch.maximum(floor, tp + fp), tp / torch.maximum(floor, tp + fn)

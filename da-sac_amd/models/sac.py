@@ -280,6 +280,7 @@ class SAC(SAC_Baseline):
         sizes and frozen BN; not for the baseline (AdaBN) mode."""
         assert self.backbone._bn_frozen(), "forward_fused: batch-statistics BN couples the samples of a pass"
         assert tuple(src_x.shape[1:]) == tuple(x.shape[1:]), "forward_fused: source and target crops must have one size"
+        ops.label_pad_mask(src_y, -1, 255)        # forward() rewrites -1 in WHATEVER labels it is given (sac.py:337-338): both passes
         ignore_mask = ops.label_pad_mask(y, -1, 255)
         losses_tgt = {}
         if update_teacher:

@@ -89,7 +89,10 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *                    zero), which saves a memset per launch.
  * dasac_conv_wgrad   partial weight gradients (split over pixels) into `workspace`;
  * dasac_conv_wgrad_finish  sums the splits, writes dW[co,ci,kh,kw] = scale[co]*G and, when `dot`
- *                    is given, dot[co] += sum_k W*G (the frozen-BN gamma gradient term); `sum_dz`
+ *                    is given (single-branch convolutions only), the frozen-BN gamma gradient term sum_k W*G as
+ *                    dasac_conv_wgrad_dot_rows(Cin, taps) PARTIAL rows dot[row][co] (row = a block of 64 input
+ *                    channels; every element is written, nothing to zero): dasac_bn_param_grads adds the rows in a
+ *                    fixed order, no atomics, so two runs give the same bits; `sum_dz`
  *                    (optional) receives sum over batch and pixels of dz per channel (d beta / d bias),
  *                    accumulated for free by the wgrad kernel while it streams dz.
  */
@@ -137,6 +140,7 @@ int dasac_conv_wgrad(const float* dz, const float* x, const int32_t* table,
 int dasac_conv_wgrad_x3(const float* dz, const float* x, const int32_t* table,
                         int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
                         void* workspace, size_t ws_bytes, dasac_stream_t stream);
+int dasac_conv_wgrad_dot_rows(int Cin, int taps);
 int dasac_conv_wgrad_finish(const void* workspace, int Nb, int OH, int OW, int M, int K,
                             const float* w, const float* scale, float* dw, float* dot,
                             float* sum_dz, int Cin, int taps, int tap0, dasac_stream_t stream);
@@ -164,14 +168,16 @@ int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, int OH, int 
  * dasac_upsample_softmax  F.interpolate(bilinear, align_corners=True) of logits [B,C,h,w]
  *     (deeplabv2.py:217, sac.py:275); optional outputs: `up` (upsampled logits), `probs` =
  *     softmax zeroed where ignore != 0 (sac.py:276,282), `class_sums[C]` (double) = sum over
- *     batch and pixels of the unmasked softmax (sac.py:108).
+ *     batch and pixels of the unmasked softmax (sac.py:108), accumulated order-independently (Q32 fixed point,
+ *     B*H*W < 2^31) so that the class prior is bit-identical from run to run.
  * dasac_upsample_bwd      transpose of the upsampling: grad_low = gscale[0] * U^T grad_up
  *     (gscale: device scalar or NULL), planes = B*C.
  * dasac_ce_loss           mode 0: mean over ALL pixels of CE(ignore 255) (deeplabv2.py:223-224,
  *     sac.py:119-132); mode 1: focal_ce_conf with its [B,B,H,W] broadcast (sac.py:134-149):
  *     loss = sum_hw (sum_i conf_i)(sum_j ce_j)/(B*B*HW).  class_weight [C] or NULL.  dlogits
  *     (optional) receives gscale[0] * d loss / d logits (gscale: device scalar = upstream
- *     gradient of the loss, NULL = 1); per_class (optional) [C] as sac.py:138-145.
+ *     gradient of the loss, NULL = 1); per_class (optional) [C] as sac.py:138-145 (order-independent Q28 fixed-point
+ *     accumulation: per-pixel values are clamped to |ce| <= 4096 there; the loss itself is not clamped).
  * dasac_warp_affine       grid_sample(x, affine_grid(theta), bilinear, zeros, align_corners=False)
  * dasac_warp_pool         sac.py:289-305 with _avg_pool (mode 0, :238-269) or _minentropy_pool
  *     (mode 1, :218-236): probs [N*T,C,H,W] -> pooled [N,C,H,W], mask [N,H,W]; `aligned`
@@ -222,17 +228,21 @@ int dasac_class_state(float* running_conf, const double* class_sums, int B, int6
  * dasac_bn_fold          frozen BatchNorm (models/__init__.py:29, basenet.py:97-100) as per-channel
  *     scale/shift for the conv epilogue: scale = gamma/sqrt(var+eps), shift = beta-(mean-b)*scale.
  * dasac_bn_param_grads   gamma/beta (and conv-bias) gradients of the folded form from
- *     dot[c] = sum dz*conv(x) (dasac_conv_wgrad_finish) and sum_dz[c] (dasac_channel_sums).
+ *     sum_rows dot[row][c] = sum dz*conv(x) (the `dot_rows` partial rows of dasac_conv_wgrad_finish) and sum_dz[c]
+ *     (dasac_channel_sums or the wgrad kernel).
  * dasac_maxpool_fwd/bwd  nn.MaxPool2d (deeplabv2.py:126 ceil_mode 3x3/2; VGG 2x2/2); caller passes
  *     the resolved OH/OW.  bwd with relu_mask folds the ReLU backward of the producer.
  * dasac_ema_update       momentum teacher (sac.py:83-102) over all tensors in one launch:
  *     out[0] = sum_t ||slow_t - fast_t||_2 (before the update); slow = slow*m + fast*(1-m).
+ *     `pairs`: device array of {const float* fast; float* slow; int64 n}; `chunks`: device (tensor, chunk) int32 pairs of
+ *     dasac_ema_chunk_elems() elements, SORTED by tensor; `sq`: scratch of n_tensors + n_chunks doubles (one partial per
+ *     chunk, added per tensor in a fixed order: the result is bit-identical from run to run).
  * dasac_scale_planes     Dropout2d with an explicit per-(n,c) keep mask (fcn.py:52,56).
  */
 int dasac_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                   const float* conv_bias, float eps, int C, float* scale, float* shift,
                   float* invstd, dasac_stream_t stream);
-int dasac_bn_param_grads(const float* dot, const float* sum_dz, const float* mean,
+int dasac_bn_param_grads(const float* dot, int dot_rows, const float* sum_dz, const float* mean,
                          const float* invstd, const float* scale, const float* conv_bias, int C,
                          float* dgamma, float* dbeta, float* dbias, dasac_stream_t stream);
 int dasac_channel_sums(const float* x, int N, int C, int64_t HW, float* out, dasac_stream_t stream);
@@ -261,6 +271,8 @@ int dasac_relu_mask(const float* dy, const float* y, float* out, int64_t n, dasa
 /* ------------------------------------------------------------------------------------------
  * Train-mode BatchNorm (baseline / AdaBN mode, models/__init__.py:29; nn.SyncBatchNorm of
  * deeplabv2.py:15, fcn.py:8; running-stat re-estimation of train.py:281-289).
+ * Both reductions are two-stage and atomic-free (one partial pair per plane and 4096-element chunk in `workspace` of
+ * dasac_bn_stats_workspace(N, C, HW) bytes, then a fixed-order sum per channel): bit-identical from run to run.
  * forward:  dasac_bn_stats (sums[0:C] = sum z, sums[C:2C] = sum z^2, doubles) -> [caller all-reduces
  *           `sums` and the element count across ranks = SyncBN] -> dasac_bn_train_finalize (batch
  *           mean / biased var -> scale, shift, mean, invstd; running stats updated with momentum and
@@ -270,7 +282,9 @@ int dasac_relu_mask(const float* dy, const float* y, float* out, int64_t n, dasa
  * `count` = elements per channel over all ranks; `count_dev` (device double, may be NULL) overrides it so
  * that an all-reduced count never has to visit the host.
  */
-int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, dasac_stream_t stream);
+size_t dasac_bn_stats_workspace(int N, int C, int64_t HW);
+int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* sums, void* workspace, size_t ws_bytes,
+                   dasac_stream_t stream);
 int dasac_bn_train_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
                             const float* beta, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked /* += 1 when given */, float momentum, float eps, int C,
@@ -279,7 +293,7 @@ int dasac_bn_train_finalize(const double* sums, double count, const double* coun
 int dasac_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu,
                    int N, int C, int64_t HW, float* y, dasac_stream_t stream);
 int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd,
-                        int N, int C, int64_t HW, double* sums, dasac_stream_t stream);
+                        int N, int C, int64_t HW, double* sums, void* workspace, size_t ws_bytes, dasac_stream_t stream);
 int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const float* invstd,
                        const float* gamma, const double* sums, double count, const double* count_dev, int N, int C,
                        int64_t HW, float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);

@@ -16,6 +16,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order: `pytest -m gpu -x` must reach the CONTRACT first -- the bit-exact kernels and the
+# oracle / golden parity of the hot path -- and the multi-process and run-vs-run self-comparison files last, so that a flake
+# in a wrapper test can never hide the parity evidence again.  Files not listed keep their alphabetical place in the middle.
+_FIRST = ["test_gpu_pseudo_labels", "test_gpu_head", "test_gpu_views", "test_gpu_photometric", "test_gpu_conv", "test_gpu_models",
+          "test_gpu_fullres", "test_gpu_bn_train", "test_gpu_optim", "test_driver_extras", "test_abi", "test_kernel_resources"]
+_LAST = ["test_gpu_bf16x3", "test_gpu_no_aten_compute", "test_gpu_sharded", "test_gpu_ddp", "test_gpu_overlap_ddp",
+         "test_gpu_zz_determinism"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if name in _FIRST:
+            return (0, _FIRST.index(name))
+        if name in _LAST:
+            return (2, _LAST.index(name))
+        return (1, 0)
+    items.sort(key=rank)          # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
@@ -31,3 +51,20 @@ def rel_err(a, b):
     a = torch.as_tensor(a).detach().to(torch.float64).cpu()
     b = torch.as_tensor(b).detach().to(torch.float64).cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def init_ranks(rank, world):
+    """Process group of a multi-rank GPU test.  On a box with at least `world` GPUs every rank takes its OWN device and the
+    transport is RCCL ("nccl" on ROCm) -- the first multi-GPU box exercises the real collectives with no code change
+    (VERDICT r3 item 10); on the usual 1-GPU box the ranks share device 0 and go through gloo (RCCL refuses two ranks on one
+    device).  DASAC_TEST_BACKEND overrides.  Returns the device index of this rank."""
+    import torch
+    import torch.distributed as dist
+    multi = torch.cuda.device_count() >= world
+    backend = os.environ.get("DASAC_TEST_BACKEND", "nccl" if multi else "gloo")
+    dev = rank if multi else 0
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dev

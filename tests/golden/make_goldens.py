@@ -585,10 +585,43 @@ def g13_photometric():
     save("g13_photometric", **rec)
 
 
+def g14_jaccard():
+    """utils/metrics.py:9-53 `Jaccard` (the validation metric of train.py:339-469) over three batches: ignore pixels, a class
+    that never occurs (17: absent from gt and from the predictions), one that is predicted but never true (18), and a few
+    gt = -1 pixels (counted as false positives of whatever is predicted there).  The class moves its counters to a GPU in
+    __init__ (`.cuda(gpu)`); on this CPU-only container that one call is made a no-op for the construction."""
+    # (the reference is already importable: import_reference() ran at module load)
+    from utils.metrics import Jaccard
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        metric = Jaccard(19, 0)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    g = torch.Generator().manual_seed(14)
+    rec = {}
+    for b in range(3):
+        logits = torch.randn(2, 19, 23, 31, generator=g) * 2
+        logits[:, 17] = -1e3
+        gt = torch.randint(0, 17, (2, 23, 31), generator=g)
+        gt[torch.rand(2, 23, 31, generator=g) < 0.15] = 255
+        gt[0, :2, :5] = -1
+        if b == 1:
+            gt[1] = 255                                   # a fully ignored image
+        pred = logits.argmax(1)
+        metric.add_sample(pred.clone(), gt.clone())       # add_sample edits its prediction argument in place
+        rec.update({"logits%d" % b: logits.numpy(), "gt%d" % b: gt.numpy(),
+                    "counts%d" % b: torch.stack([metric.tps, metric.fps, metric.fns]).to(torch.int64).numpy()})
+    j, p, r = metric.summarise()
+    rec.update(jaccards=j.numpy(), precision=p.numpy(), recall=r.numpy())
+    print("g14: mIoU", float(j.mean()), "tp", metric.tps.sum().item())
+    save("g14_jaccard", **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11", "g12", "g13", "g14"]
     table = dict(g3=g3_bilinear, g4=g4_refine, g5=g5_pseudo_labels, g6=g6_losses, g7=g7_state_sequences,
                  g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture, g11=g11_index_tables, g12=g12_views,
-                 g13=g13_photometric)
+                 g13=g13_photometric, g14=g14_jaccard)
     for w in which:
         table[w]()

@@ -52,6 +52,33 @@ def test_iou_counts_kernel_matches_reference_definition():
         assert counts[:, c].tolist() == [2 * tp, 2 * fp, 2 * fn]
 
 
+def test_summarise_iou_matches_reference_golden_g14(golden):
+    """utils/metrics.py:40-53 on the reference's own accumulated counts (CPU: host arithmetic only)."""
+    import driver
+    g = golden("g14_jaccard")
+    j, p, r = driver.summarise_iou(torch.from_numpy(g["counts2"]))
+    assert torch.equal(j, torch.from_numpy(g["jaccards"])) and torch.equal(p, torch.from_numpy(g["precision"]))
+    assert torch.equal(r, torch.from_numpy(g["recall"]))
+    assert float(j[17]) == 0.0 and float(j[18]) == 0.0            # never occurring / predicted but never true
+
+
+@pytest.mark.gpu
+def test_iou_counts_kernel_matches_reference_golden_g14(golden):
+    """The reference's `Jaccard.add_sample` (utils/metrics.py:19-38) run over three batches -- ignore pixels, a fully ignored
+    image, gt = -1 pixels, an absent class, a never-true class -- against the one-pass count kernel: the integer counts
+    after EVERY batch and the summary are equal."""
+    import driver
+    from dasac_hip import ops
+    g = golden("g14_jaccard")
+    counts = None
+    for b in range(3):
+        counts = ops.iou_counts(torch.from_numpy(g["logits%d" % b]).cuda(), torch.from_numpy(g["gt%d" % b]).cuda(), counts)
+        assert torch.equal(counts.cpu(), torch.from_numpy(g["counts%d" % b])), b
+    j, p, r = driver.summarise_iou(counts)
+    assert torch.equal(j, torch.from_numpy(g["jaccards"])) and torch.equal(p, torch.from_numpy(g["precision"]))
+    assert torch.equal(r, torch.from_numpy(g["recall"]))
+
+
 @pytest.mark.gpu
 def test_fused_inference_labels_match_oracle():
     """infer_val.py:160-163 + argmax + convert_to_cs as one kernel: label maps equal the oracle's except where the

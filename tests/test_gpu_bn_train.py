@@ -129,7 +129,8 @@ def _syncbn_rank(rank, port, q):
         if p_ not in sys.path:
             sys.path.insert(0, p_)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from conftest import init_ranks
+    dev = init_ranks(rank, 2)
     import models
     import driver
     cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False, BASELINE=True))
@@ -137,7 +138,7 @@ def _syncbn_rank(rank, port, q):
     net.backbone.load_state_dict(N.resnet101_state(seed=4, randomize_bn=True, he_init=True, residual_gain=0.25, aspp_gain=0.2), strict=True)
     net.cuda().train()
     optim = driver.make_optimizer(net, cfg)
-    ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    ddp = nn.parallel.DistributedDataParallel(net, device_ids=[dev])
     xs, ys, xt = _sync_data(rank)
     losses = driver.baseline_train_iteration(ddp, optim, (xs.cuda(), ys.cuda()), xt.cuda())
     torch.cuda.synchronize()

@@ -83,11 +83,12 @@ def _ddp_rank(rank, world, port, q):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import init_ranks
+    dev = init_ranks(rank, world)
     import driver
     cfg, net = _build()
     optim = driver.make_optimizer(net, cfg)
-    ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    ddp = nn.parallel.DistributedDataParallel(net, device_ids=[dev])
     src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=50 + rank)
     losses = _two_backward_passes(ddp, src, tgt, cfg.LR_TARGET)
     optim.step()

@@ -38,6 +38,24 @@ def test_cfg3_resolution_sample_matches_the_oracle(fuse):
     assert cmp_["param_max_err_over_tensor_max"] <= 1e-5
 
 
+def test_full_resolution_head_parity_eight_crops_four_views():
+    """VERDICT r3 missing 4: the multi-view head at cfg-3's size with B = 8 crops and L = 4 views per group -- the T = 4 fusion
+    of models/sac.py:238-269,289-311 and the [B,B,H,W] broadcast of :148 -- against oracle.head_ref at 769 x 769 (head only, so
+    the oracle takes seconds): refined probabilities and the warped diagnostics, class prior, the label map with torch.equal on
+    equal probabilities through the module's threshold path, loss value and d loss / d (stride-8 logits)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    dt, c = bench.head_parity_fullres(769, groups=2, views=4)
+    print("head_parity_fullres:", c, "oracle seconds", round(dt, 1))
+    assert c["crops"] == 8 and c["views_per_group"] == 4 and c["labelled_frac"] > 0.3
+    assert c["refined_max_abs"] <= 1e-5 and c["teacher_aligned_max_abs"] <= 1e-5 and c["frames_aligned_rel"] <= 1e-5
+    assert c["running_conf_max_abs"] <= 1e-7
+    assert c["labels_equal_on_equal_probs"] and c["conf_equal_on_equal_probs"]          # the bit-exact contract
+    assert c["label_mismatch_frac_end_to_end"] < 1e-4                                   # probabilities differ at 1e-6: borderline pixels
+    assert c["self_ce_rel"] <= 1e-5 and c["self_ce_rel_end_to_end"] <= 1e-3
+    assert c["dlogits_max_err_over_tensor_max"] <= 1e-4
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without torch.distributed.run (what the driver runs for the scaling curve): two ranks, here
     both on the single device of the box (DASAC_BENCH_RANKS_PER_GPU=2 -> gloo transport), tiny crops; exactly one JSON line

@@ -285,6 +285,16 @@ def test_label_pad_mask_class_sums_and_dropout_planes():
     assert abs(float((a == 0).float().mean()) - 0.1) < 5e-3 and not torch.equal(a, b)       # Bernoulli(0.9), a new draw per call
     rows = (a == 0).float().mean(1)
     assert float(rows.std()) < 0.02                                                          # no structure across planes
+    # the stream is torch's CUDA generator: re-seeding and get/set_rng_state (checkpoint resume) replay the masks
+    torch.cuda.manual_seed(11)
+    assert torch.equal(ops.dropout_planes(64, 4096, 0.1, torch.device("cuda", 0)), a)
+    state = torch.cuda.get_rng_state(0)
+    c = ops.dropout_planes(64, 4096, 0.1, torch.device("cuda", 0))
+    assert torch.equal(c, b)
+    torch.cuda.set_rng_state(state, 0)
+    assert torch.equal(ops.dropout_planes(64, 4096, 0.1, torch.device("cuda", 0)), c)
+    torch.cuda.manual_seed(12)
+    assert not torch.equal(ops.dropout_planes(64, 4096, 0.1, torch.device("cuda", 0)), a)
 
 
 def test_loss_shortcut_to_low_resolution_is_dropped_when_logits_up_is_edited_or_watched():

@@ -416,9 +416,9 @@ def test_fused_iteration_equals_the_two_pass_iteration_and_the_oracle(wrapped):
         # the teacher side does not depend on how the student is batched: bit-equal on equal weights (iteration 0)
         if it == 0:
             assert torch.equal(o0["teacher_labels"], o1["teacher_labels"]) and torch.equal(o0["teacher_refined"], o1["teacher_refined"])
-            assert float(ls0["loss_ce"]) == pytest.approx(float(ls1["loss_ce"]), rel=1e-6)
-            assert float(lt0["self_ce"]) == pytest.approx(float(lt1["self_ce"]), rel=1e-6)
-            assert float(lt0["loss_ce"]) == pytest.approx(float(lt1["loss_ce"]), rel=1e-6)
+            assert float(ls0["loss_ce"]) == pytest.approx(float(ls1["loss_ce"]), rel=1e-5)
+            assert float(lt0["self_ce"]) == pytest.approx(float(lt1["self_ce"]), rel=1e-5)
+            assert float(lt0["loss_ce"]) == pytest.approx(float(lt1["loss_ce"]), rel=1e-5)
             # one optimiser step from equal weights: the two schedules differ by the summation order of the weight-gradient
             # reductions only (4 crops at once instead of 2 + 2) -- and both sit on the oracle's parameters
             sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()

@@ -48,13 +48,13 @@ def test_gradient_sink_matches_the_plain_module_and_grads_share_one_buffer():
     cfg, net2 = _build()
     wrapped = OverlappedDataParallel(net2, device_ids=[0], bucket_mb=8)
     got = _two_passes(wrapped, src, tgt, cfg.LR_TARGET)
-    assert plain == pytest.approx(got, rel=1e-6)
+    assert plain == pytest.approx(got, rel=1e-5)
     n_checked = 0
     for n, p in net2.named_parameters():
         if n in ref:
-            # The sink only changes WHERE gradients are written.  Two runs of the same iteration are not bit-reproducible
-            # themselves (the class-prior sums and d-gamma's dot term are combined with atomics, whose order varies from
-            # launch to launch: a last-bit difference in chi moves every target-pass gradient by ~1e-7), hence a tolerance.
+            # The sink only changes WHERE gradients are written.  Since round 4 every reduction of an iteration is
+            # order-independent (tests/test_gpu_zz_determinism.py holds two runs to torch.equal); comparisons ACROSS code
+            # paths (sink / no sink, wrapper / no wrapper) still carry 1e-5, never tighter.
             assert float((p.grad - ref[n]).abs().max()) <= 1e-5 * float(ref[n].abs().max()) + 1e-12, n
             n_checked += 1
     assert n_checked == len(ref) == 320
@@ -80,10 +80,10 @@ def test_stepping_through_the_wrapper_matches_the_plain_driver():
             losses.append((float(ls["loss_ce"]), float(lt["self_ce"])))
         out.append((losses, {k: v.clone() for k, v in net.backbone.state_dict().items()}))
     for a, b in zip(out[0][0], out[1][0]):
-        assert a == pytest.approx(b, rel=1e-6)
+        assert a == pytest.approx(b, rel=1e-5)
     for k in out[0][1]:
         a, b = out[0][1][k].float(), out[1][1][k].float()
-        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-12, k
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12, k
 
 
 def _rank_main(rank, world, port, q, use_torch_ddp):
@@ -93,7 +93,8 @@ def _rank_main(rank, world, port, q, use_torch_ddp):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import init_ranks
+    dev = init_ranks(rank, world)
     import driver
     from dasac_hip.parallel import OverlappedDataParallel
     cfg, net = _build(seed=3 + rank)               # DIFFERENT initial weights per rank: construction must broadcast rank 0's
@@ -104,9 +105,9 @@ def _rank_main(rank, world, port, q, use_torch_ddp):
         net.broadcast_frozen_buffers()             # stock DDP never sends the exempt buffers: the trainer does it once
     optim = driver.make_optimizer(net, cfg)
     if use_torch_ddp:
-        ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+        ddp = nn.parallel.DistributedDataParallel(net, device_ids=[dev])
     else:
-        ddp = OverlappedDataParallel(net, device_ids=[0], bucket_mb=8)
+        ddp = OverlappedDataParallel(net, device_ids=[dev], bucket_mb=8)
     src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=50 + rank)
     losses = _two_passes(ddp, src, tgt, cfg.LR_TARGET)
     grads = {k: p.grad.detach().cpu().numpy() for k, p in net.backbone.named_parameters() if k in _PROBE}
@@ -165,9 +166,9 @@ def test_two_ranks_overlapped_reduction_equals_the_manual_mean_and_stock_ddp():
     for k in _PROBE:
         ref = ((grads[0][k] + grads[1][k]) / 2).cpu()
         out = torch.from_numpy(got[0][3][k])
-        assert float((ref - out).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-12, k
+        assert float((ref - out).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, k
     # and the stock DistributedDataParallel wrapper over the same engine gives the same parameters after the step
     stock = _spawn(True)
     for k in _PROBE:
         a, b = torch.from_numpy(got[0][2][k]), torch.from_numpy(stock[0][2][k])
-        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, k
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, k

@@ -57,7 +57,8 @@ def _rank_main(rank, port, arch, q):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from conftest import init_ranks
+    dev = init_ranks(rank, WORLD)
     import driver
     import models
     make_sd, hw, probe = ARCHS[arch]
@@ -67,7 +68,7 @@ def _rank_main(rank, port, arch, q):
     net.backbone.load_state_dict(make_sd(), strict=True)
     net.cuda().train()
     optim = driver.make_optimizer(net, cfg)
-    ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    ddp = nn.parallel.DistributedDataParallel(net, device_ids=[dev])
     rec = []
     for it in range(ITERS):
         src, loaded = _batches(rank, it, hw)
