@@ -71,6 +71,11 @@ struct Epilogue {
   const unsigned* mbits;   // consumer: out = bit ? out : 0    (exclusive with `mask`)
   unsigned* obits;         // producer: bit = out > 0 (after ReLU); ostride must be 1
   int w32;
+  // BITS == 3 (batch-statistics BatchNorm behind this conv, deeplabv2.py:15 in baseline / AdaBN mode): the epilogue also
+  // leaves, per 128-pixel tile, the per-channel sum and sum of squares of what it stores -- stats[pixel tile][0|1][Mpad] --
+  // so that the stand-alone statistics pass over z (one full read of the activation per BN layer) disappears.  Every slot
+  // of a tile is written by exactly one workgroup; a fixed-order sum over the tiles follows (bn_train_finalize): deterministic.
+  float* stats;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -148,6 +153,20 @@ __device__ __forceinline__ void split_bf16(f32x4 v0, f32x4 v1, f32x4& heads, f32
     heads[p] = __uint_as_float(h);
     tails[p] = __uint_as_float(pack_bf16(t0, t1));
   }
+}
+
+// sum over the 32 lanes of a half-wave (all of them end up with it): four DPP adds inside each row of 16 lanes (quad
+// permutes, half-row and row mirrors) and one cross-row exchange
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);     // row_half_mirror
+  v = dpp_add<0x140>(v);     // row_mirror
+  return v + __shfl_xor(v, 16, 64);
 }
 
 // LDS tiles are k-interleaved: element (k, x) of a K-step lives at [(k/4)][x][k%4], so that
@@ -469,6 +488,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
     const bool deposited = STREAMK && ks > 0;                // this worker only contributed a partial sum
     DASAC_STAMP(2);
     if (!deposited) {
+    if constexpr (BITS != 3) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int pix = n0 + wn * WN + j * 32 + li;
@@ -534,6 +554,76 @@ __global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const flo
           // (a 32-pixel group of the last tile may lie entirely past the last pixel: no word exists for it)
           if (lane < 32 && mrow + lane < g.M && wcol < ep.w32) ep.obits[(size_t)(mrow + lane) * ep.w32 + wcol] = (unsigned)bitrows;
         }
+      }
+    }
+    } else {
+      // ---- BITS == 3: raw convolution (+ bias) in front of a batch-statistics BatchNorm.  No residual / ReLU / mask here (they
+      // follow the normalisation); instead the per-row sum and sum of squares of the stored values.  Row groups are the OUTER
+      // loop so that only one group's 2 x 16 running sums are live next to the accumulators.  Lane (li, lh) holds, per
+      // accumulator register rg, the sum over ITS pixels of row i*32 + (rg&3) + 8*(rg>>2) + 4*lh: sum over the 32 lanes of
+      // the half-wave, lane li == rg keeps row rg's total, the WAVES_N waves of a row meet in LDS (the operand tiles are
+      // dead: the K loop ended with a barrier), 2*BM coalesced floats go out per tile.
+      static_assert(BITS != 3 || (BM == 128 && WAVES_N == 2 && TN == 2), "stats epilogue: 128-row tile, two pixel waves");
+      float* sst = reinterpret_cast<float*>(&sA[0][0]);        // [2][BM][WAVES_N]
+      unsigned vo[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int pix = n0 + wn * WN + j * 32 + li;
+        vo[j] = kPoison;
+        if (pix < g.Npix) {
+          const int n = pix / OHW, r = pix - n * OHW;
+          const int oh = r / g.OW, ow = r - oh * g.OW;
+          vo[j] = (unsigned)(n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHW) * 4u;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mrow = m0 + wm * WM + i * 32;
+        float ms = 0.f, mq = 0.f;
+        if (mrow < g.M) {                                        // (uniform) a whole 32-row group beyond M contributes zeros
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            float sh[8];
+            bool rowok[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int rg = half * 8 + u;
+              const int mr = mrow + (rg & 3) + 8 * (rg >> 2);
+              rowok[u] = ragged ? (mr + 4 * lh < g.M) : (mr < g.M);
+              sh[u] = ep.shift ? buf_f32(rsh, rowok[u] ? (unsigned)(4 * lh) * 4u : kPoison, mr * 4) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int rg = half * 8 + u;
+              const int roff = (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4;
+              float ss = 0.f, qq = 0.f;
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const float v = acc[i][j][rg] + sh[u];
+                const unsigned vr = rowok[u] ? vo[j] : kPoison;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vr, roff, 0);
+                const float vv = vr != kPoison ? v : 0.f;        // pixels / rows past the tensor count as 0
+                ss += vv;
+                qq = __builtin_fmaf(vv, vv, qq);
+              }
+              const float rs_ = half_wave_sum(ss), rq_ = half_wave_sum(qq);
+              ms = li == rg ? rs_ : ms;
+              mq = li == rg ? rq_ : mq;
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+        if (li < 16) {
+          const int row = wm * WM + i * 32 + (li & 3) + 8 * (li >> 2) + 4 * lh;
+          sst[row * WAVES_N + wn] = ms;
+          sst[(BM + row) * WAVES_N + wn] = mq;
+        }
+      }
+      __syncthreads();
+      {
+        const int which = t / BM, row = t - which * BM;          // 256 threads = {sum, sum of squares} x 128 rows
+        const float tot = sst[(which * BM + row) * WAVES_N] + sst[(which * BM + row) * WAVES_N + 1];
+        ep.stats[((size_t)(n0 / BN) * 2 + which) * g.Mpad + m0 + row] = tot;
       }
     }
     }
@@ -1340,8 +1430,11 @@ extern "C" int dasac_conv_gemm_bits_ok(int M, int Cx) { return (pick_bm(dasac_co
 static int conv_gemm_impl(bool x3, const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx, int H,
                           int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride, const float* shift,
                           const float* res, const float* mask, const uint32_t* mask_bits, uint32_t* relu_bits_out, int relu,
-                          int pix_begin, int pix_count, int schedule, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+                          int pix_begin, int pix_count, int schedule, void* workspace, size_t ws_bytes, dasac_stream_t stream,
+                          float* stats = nullptr) {
   DASAC_REQUIRE(x && packed && table && out, "conv_gemm: null pointer");
+  DASAC_REQUIRE(!stats || (!x3 && !mask_bits && !relu_bits_out && dasac_conv_gemm_bits_ok(M, Cx) && ostride == 1),
+                "conv_gemm_stats: needs the 128-row fp32 tile with Cx %% 16 == 0 (dasac_conv_gemm_stats_ok), no bit masks");
   DASAC_REQUIRE(!(mask && mask_bits), "conv_gemm: give the ReLU pattern as fp32 mask OR as bit mask");
   DASAC_REQUIRE(!(mask_bits || relu_bits_out) || (ostride == 1 && OutH == OH && OutW == OW),
                 "conv_gemm: bit masks index the GEMM's own pixel axis (ostride must be 1)");
@@ -1353,7 +1446,7 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
   if (rc) return rc;
   DASAC_REQUIRE((int64_t)dasac_conv_kpad(K) * Mpad * 4 < (1ll << 31), "conv: packed weights exceed 2 GiB");
   g.w_bytes = dasac_conv_kpad(K) * Mpad * 4;
-  Epilogue ep{shift, res, mask, relu, mask_bits, relu_bits_out, (g.Npix + 31) / 32};
+  Epilogue ep{shift, res, mask, relu, mask_bits, relu_bits_out, (g.Npix + 31) / 32, stats};
   DASAC_REQUIRE((int64_t)M * ep.w32 * 4 < (1ll << 31), "conv_gemm: bit mask exceeds the 2 GiB buffer-descriptor window");
   const int4* tab = reinterpret_cast<const int4*>(table);
   hipStream_t s = as_stream(stream);
@@ -1378,6 +1471,12 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
                 : launch_gemm<64, 128, 2, kBK, false, true>(x, packed, tab, out, g, ep, n_tiles, 1, nullptr, 0, s);
     if (rc) return rc;
     DASAC_CHECK_LAUNCH("conv_gemm_x3");
+    return DASAC_OK;
+  }
+  if (stats) {
+    rc = launch_gemm<128, 128, 2, kBK, true, false, 3>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
+    if (rc) return rc;
+    DASAC_CHECK_LAUNCH("conv_gemm_stats");
     return DASAC_OK;
   }
   if (mask_bits || relu_bits_out) {
@@ -1415,6 +1514,20 @@ extern "C" int dasac_conv_gemm(const float* x, const float* packed, const int32_
                                void* workspace, size_t ws_bytes, dasac_stream_t stream) {
   return conv_gemm_impl(false, x, packed, table, out, Nb, Cx, H, W, OH, OW, stride, M, K, OutH, OutW, ostride, shift, res, mask,
                         mask_bits, relu_bits_out, relu, pix_begin, pix_count, schedule, workspace, ws_bytes, stream);
+}
+
+// dasac_conv_gemm whose epilogue also leaves per-tile channel statistics (batch-statistics BatchNorm behind the conv):
+// stats [dasac_conv_gemm_stats_tiles(Nb, OH, OW)][2][dasac_conv_mpad(M)] floats = per 128-pixel tile the sum and the sum of
+// squares of every output row as stored (shift / bias included) -- dasac_bn_train_finalize adds the tiles in a fixed order.
+extern "C" int dasac_conv_gemm_stats_ok(int M, int Cx) { return dasac_conv_gemm_bits_ok(M, Cx); }
+extern "C" int dasac_conv_gemm_stats_tiles(int Nb, int OH, int OW) { return (int)(((int64_t)Nb * OH * OW + 127) / 128); }
+extern "C" int dasac_conv_gemm_stats(const float* x, const float* packed, const int32_t* table, float* out, int Nb, int Cx,
+                                     int H, int W, int OH, int OW, int stride, int M, int K, int OutH, int OutW, int ostride,
+                                     const float* shift, const float* res, int relu, int pix_begin, int pix_count, int schedule,
+                                     void* workspace, size_t ws_bytes, float* stats, dasac_stream_t stream) {
+  DASAC_REQUIRE(stats, "conv_gemm_stats: null statistics buffer");
+  return conv_gemm_impl(false, x, packed, table, out, Nb, Cx, H, W, OH, OW, stride, M, K, OutH, OutW, ostride, shift, res, nullptr,
+                        nullptr, nullptr, relu, pix_begin, pix_count, schedule, workspace, ws_bytes, stream, stats);
 }
 
 extern "C" int dasac_conv_gemm_x3(const float* x, const void* packed_x3, const int32_t* table, float* out, int Nb, int Cx,

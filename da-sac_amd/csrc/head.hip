@@ -711,7 +711,75 @@ __global__ __launch_bounds__(kHB) void warp_pool(const float* __restrict__ probs
   }
 }
 
+// The default configuration (avg pooling of TT <= 4 warped views, CT classes known at compile time) with the memory-level
+// parallelism the generic kernel above lacks: that one walks the views one after the other and, the class count being a
+// runtime value, gets four dependent-looking gathers in flight at a time -- 1.5 TB/s of algorithmic bytes, latency-bound.
+// Here the T sample descriptors of a pixel are built first, then every class issues its 4*T taps as ONE batch (16 independent
+// loads for T = 4; the unrolled class loop lets the compiler run several classes ahead).  Same arithmetic in the same order
+// (per class S = ((a0*cov0 + a1*cov1) + a2*cov2) + a3*cov3 accumulated from 0 in view order, then Z, mask, S / max(Z, 1e-3)):
+// bit-identical to the generic kernel, which stays for min-entropy pooling, pre-aligned views, T > 4 and other class counts.
+template <int CT, int TT>
+__global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ probs, const float* __restrict__ theta,
+                                                     const float* __restrict__ theta_inv, int H, int W, float tol,
+                                                     float* __restrict__ aligned, float* __restrict__ pooled,
+                                                     float* __restrict__ mask, int blocks_per_group) {
+  const int n = blockIdx.x / blocks_per_group, chunk = blockIdx.x % blocks_per_group;
+  const int HW = H * W;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_group * kHB) {
+    const int oy = p / W, ox = p - oy * W;
+    Sample s[TT];
+    float cov[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const int b = n * TT + t;
+      s[t] = make_sample(theta + b * 6, oy, ox, H, W);
+      const Sample si = make_sample(theta_inv + b * 6, oy, ox, H, W);
+      cov[t] = si.w00 + si.w01 + si.w10 + si.w11;
+    }
+    float S[CT];
+    float Z = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      float a[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) a[t] = take(probs + ((size_t)(n * TT + t) * CT + c) * HW, s[t]);
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (aligned) aligned[((size_t)(n * TT + t) * CT + c) * HW + p] = a[t];
+        acc += a[t] * cov[t];
+      }
+      S[c] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) Z += S[c];
+    const float den = fmaxf(Z, 1e-3f);
+    mask[(size_t)n * HW + p] = Z > tol ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) pooled[((size_t)n * CT + c) * HW + p] = S[c] / den;
+  }
+}
+
 // refined[b] = sample(pooled[g(b)], theta_inv[b]) * sample(mask[g(b)], theta_inv[b]),  g(b) = group_of[b]
+// CT > 0: compile-time class count -- the class loop is unrolled and all 4*CT taps of a pixel are independent loads in flight
+template <int CT>
+__global__ __launch_bounds__(kHB) void warp_back_ct(const float* __restrict__ pooled, const float* __restrict__ mask,
+                                                    const float* __restrict__ theta_inv, int group_div, int H, int W,
+                                                    float* __restrict__ refined, int blocks_per_image) {
+  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
+  const int n = b / group_div;
+  const int HW = H * W;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const Sample s = make_sample(theta_inv + b * 6, p / W, p % W, H, W);
+    const float mv = take(mask + (size_t)n * HW, s);
+    float v[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) v[c] = take(pooled + ((size_t)n * CT + c) * HW, s);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) refined[((size_t)b * CT + c) * HW + p] = v[c] * mv;
+  }
+}
+
 __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ pooled, const float* __restrict__ mask,
                                                  const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
                                                  float* __restrict__ refined, int blocks_per_image) {
@@ -904,8 +972,15 @@ extern "C" int dasac_warp_pool(const float* probs, const float* theta, const flo
   DASAC_REQUIRE(probs && pooled && mask && ((theta && theta_inv) || (!theta && !theta_inv && !aligned)), "warp_pool: null pointer");
   DASAC_REQUIRE(N > 0 && T > 0 && C > 0 && C <= kMaxC && (mode == 0 || mode == 1), "warp_pool: bad arguments");
   const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + N - 1) / N);
-  hipLaunchKernelGGL(warp_pool, dim3(per * N), dim3(kHB), 0, as_stream(stream), probs, theta, theta_inv, T, C, H, W, mode,
-                     tolerance, aligned, pooled, mask, per);
+  hipStream_t s = as_stream(stream);
+#define DASAC_WPA(TT) hipLaunchKernelGGL((warp_pool_avg<19, TT>), dim3(per * N), dim3(kHB), 0, s, probs, theta, theta_inv, H, W, tolerance, aligned, pooled, mask, per)
+  if (mode == 0 && theta && C == 19 && T == 4) DASAC_WPA(4);
+  else if (mode == 0 && theta && C == 19 && T == 2) DASAC_WPA(2);
+  else if (mode == 0 && theta && C == 19 && T == 1) DASAC_WPA(1);
+  else
+    hipLaunchKernelGGL(warp_pool, dim3(per * N), dim3(kHB), 0, s, probs, theta, theta_inv, T, C, H, W, mode, tolerance, aligned, pooled,
+                       mask, per);
+#undef DASAC_WPA
   DASAC_CHECK_LAUNCH("warp_pool");
   return DASAC_OK;
 }
@@ -914,8 +989,12 @@ extern "C" int dasac_warp_back(const float* pooled, const float* mask, const flo
                                int C, int H, int W, float* refined, dasac_stream_t stream) {
   DASAC_REQUIRE(pooled && mask && theta_inv && refined && B > 0 && views_per_group > 0, "warp_back: bad arguments");
   const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
-  hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
-                     W, refined, per);
+  if (C == 19)
+    hipLaunchKernelGGL(warp_back_ct<19>, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, H, W,
+                       refined, per);
+  else
+    hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
+                       W, refined, per);
   DASAC_CHECK_LAUNCH("warp_back");
   return DASAC_OK;
 }

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int
 
 // sums[c] = sum over (n, chunk) of the s-partials, sums[C + c] = of the q-partials; grid C, one wave each
 __global__ __launch_bounds__(64) void bn_sums_finish(const double* __restrict__ partial, int N, int C, int chunks,
-                                                     double* __restrict__ sums) {
+                                                     double* __restrict__ sums, float* __restrict__ out0,
+                                                     float* __restrict__ out1) {
   const int c = blockIdx.x;
   double s = 0, q = 0;
   for (int j = threadIdx.x; j < N * chunks; j += 64) {
@@ -490,11 +491,31 @@ __global__ __launch_bounds__(64) void bn_sums_finish(const double* __restrict__ 
   if (threadIdx.x == 0) {
     sums[c] = s;
     sums[C + c] = q;
+    if (out0) out0[c] = (float)s;       // backward: d beta = sum dy, d gamma = sum dy*xhat of THIS rank (no extra launch)
+    if (out1) out1[c] = (float)q;
   }
 }
 
+// per-tile channel statistics left by dasac_conv_gemm_stats -> sums[c], sums[C + c] (doubles): a thread per channel adds the
+// tiles in ascending order (coalesced across the channels of a block; fixed order = deterministic)
+__global__ __launch_bounds__(64) void bn_tile_stats_reduce(const float* __restrict__ ts, int n_tiles, int C, int Mpad,
+                                                           double* __restrict__ sums) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+#pragma unroll 4
+  for (int i = 0; i < n_tiles; ++i) {
+    s += (double)ts[(size_t)(2 * i) * Mpad + c];
+    q += (double)ts[(size_t)(2 * i + 1) * Mpad + c];
+  }
+  sums[c] = s;
+  sums[C + c] = q;
+}
+
 // batch mean / biased var -> scale, shift, mean, invstd; running stats: momentum update with the unbiased var
-__global__ void bn_train_finalize(const double* __restrict__ sums, double count_host, const double* __restrict__ count_dev,
+// `sums` null: the sums come from `tile_stats` (dasac_conv_gemm_stats), added here in tile order -- one launch per BN layer
+__global__ void bn_train_finalize(const double* __restrict__ sums, const float* __restrict__ tile_stats, int n_tiles, int Mpad,
+                                  double count_host, const double* __restrict__ count_dev,
                                   const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float* __restrict__ running_mean,
                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked, float momentum,
@@ -505,8 +526,20 @@ __global__ void bn_train_finalize(const double* __restrict__ sums, double count_
   if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;      // nn.BatchNorm bookkeeping, no extra launch
   if (c >= C) return;
   const double count = count_dev ? count_dev[0] : count_host;   // SyncBN: the all-reduced count stays on the device
-  const double m = sums[c] / count;
-  double var = sums[C + c] / count - m * m;
+  double s1, s2;
+  if (sums) {
+    s1 = sums[c];
+    s2 = sums[C + c];
+  } else {
+    s1 = s2 = 0;
+#pragma unroll 4
+    for (int i = 0; i < n_tiles; ++i) {
+      s1 += (double)tile_stats[(size_t)(2 * i) * Mpad + c];
+      s2 += (double)tile_stats[(size_t)(2 * i + 1) * Mpad + c];
+    }
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
   if (var < 0) var = 0;
   const float meanf = (float)m, varf = (float)var;
   const float is = 1.f / sqrtf(varf + eps);
@@ -602,8 +635,21 @@ extern "C" int dasac_bn_stats(const float* z, int N, int C, int64_t HW, double* 
   double* partial = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(bn_stats, dim3((unsigned)chunks, N * C), dim3(256), 0, s, z, C, (int)HW, partial);
   DASAC_CHECK_LAUNCH("bn_stats");
-  hipLaunchKernelGGL(bn_sums_finish, dim3(C), dim3(64), 0, s, partial, N, C, chunks, sums);
+  hipLaunchKernelGGL(bn_sums_finish, dim3(C), dim3(64), 0, s, partial, N, C, chunks, sums, (float*)nullptr, (float*)nullptr);
   DASAC_CHECK_LAUNCH("bn_sums_finish");
+  return DASAC_OK;
+}
+
+static int bn_finalize_launch(const double* sums, const float* tile_stats, int n_tiles, int mpad, double count,
+                              const double* count_dev, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int C, float* scale,
+                              float* shift, float* mean, float* invstd, dasac_stream_t stream) {
+  DASAC_REQUIRE((sums || (tile_stats && n_tiles > 0 && mpad >= C)) && gamma && beta && scale && shift && mean && invstd && C > 0 &&
+                    (count > 0 || count_dev),
+                "bn_train_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_train_finalize, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), sums, tile_stats, n_tiles, mpad, count,
+                     count_dev, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, C, scale, shift, mean, invstd);
+  DASAC_CHECK_LAUNCH("bn_train_finalize");
   return DASAC_OK;
 }
 
@@ -611,11 +657,25 @@ extern "C" int dasac_bn_train_finalize(const double* sums, double count, const d
                                        const float* beta, float* running_mean, float* running_var,
                                        int64_t* num_batches_tracked, float momentum, float eps, int C, float* scale,
                                        float* shift, float* mean, float* invstd, dasac_stream_t stream) {
-  DASAC_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && (count > 0 || count_dev),
-                "bn_train_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_train_finalize, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count, count_dev, gamma, beta,
-                     running_mean, running_var, num_batches_tracked, momentum, eps, C, scale, shift, mean, invstd);
-  DASAC_CHECK_LAUNCH("bn_train_finalize");
+  DASAC_REQUIRE(sums, "bn_train_finalize: null sums");
+  return bn_finalize_launch(sums, nullptr, 0, 0, count, count_dev, gamma, beta, running_mean, running_var, num_batches_tracked,
+                            momentum, eps, C, scale, shift, mean, invstd, stream);
+}
+
+extern "C" int dasac_bn_train_finalize_tiles(const float* tile_stats, int n_tiles, int mpad, double count, const float* gamma,
+                                             const float* beta, float* running_mean, float* running_var,
+                                             int64_t* num_batches_tracked, float momentum, float eps, int C, float* scale,
+                                             float* shift, float* mean, float* invstd, dasac_stream_t stream) {
+  DASAC_REQUIRE(tile_stats, "bn_train_finalize_tiles: null statistics");
+  return bn_finalize_launch(nullptr, tile_stats, n_tiles, mpad, count, nullptr, gamma, beta, running_mean, running_var,
+                            num_batches_tracked, momentum, eps, C, scale, shift, mean, invstd, stream);
+}
+
+extern "C" int dasac_bn_tile_stats_reduce(const float* tile_stats, int n_tiles, int C, int mpad, double* sums,
+                                          dasac_stream_t stream) {
+  DASAC_REQUIRE(tile_stats && sums && n_tiles > 0 && C > 0 && mpad >= C, "bn_tile_stats_reduce: bad arguments");
+  hipLaunchKernelGGL(bn_tile_stats_reduce, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), tile_stats, n_tiles, C, mpad, sums);
+  DASAC_CHECK_LAUNCH("bn_tile_stats_reduce");
   return DASAC_OK;
 }
 
@@ -630,7 +690,8 @@ extern "C" int dasac_bn_apply(const float* z, const float* scale, const float* s
 }
 
 extern "C" int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd, int N, int C,
-                                   int64_t HW, double* sums, void* workspace, size_t ws_bytes, dasac_stream_t stream) {
+                                   int64_t HW, double* sums, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
+                                   dasac_stream_t stream) {
   DASAC_REQUIRE(dy && z && mean && invstd && sums && workspace && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31),
                 "bn_bwd_reduce: bad arguments");
   if (ws_bytes < dasac_bn_stats_workspace(N, C, HW)) return fail(DASAC_EWORKSPACE, "bn_bwd_reduce: workspace too small");
@@ -639,7 +700,7 @@ extern "C" int dasac_bn_bwd_reduce(const float* dy, const float* z, const float*
   double* partial = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(bn_bwd_reduce, dim3((unsigned)chunks, N * C), dim3(256), 0, s, dy, z, mean, invstd, C, (int)HW, partial);
   DASAC_CHECK_LAUNCH("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_sums_finish, dim3(C), dim3(64), 0, s, partial, N, C, chunks, sums);
+  hipLaunchKernelGGL(bn_sums_finish, dim3(C), dim3(64), 0, s, partial, N, C, chunks, sums, dbeta, dgamma);
   DASAC_CHECK_LAUNCH("bn_sums_finish");
   return DASAC_OK;
 }

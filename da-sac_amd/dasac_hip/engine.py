@@ -286,7 +286,9 @@ class Engine:
     def _refresh_plan(self, device, transposed):
         """Device job tables for `ops.refresh_network`: one fold job per frozen-BN conv, one pack job per (conv, layout) for
         every single-branch, non-expanded conv.  Output buffers are persistent (their pointers sit in the tables)."""
-        key = (device.index, bool(transposed))
+        # batch-statistics BN layers (baseline / AdaBN mode) fold nothing into the weights: their convs are packed un-scaled
+        bn_mode = tuple(bool(op.bn is not None and op.bn.training) for op in self.plan.ops if op.kind == "conv")
+        key = (device.index, bool(transposed), bn_mode)
         plan = self._refresh.get(key)
         if plan is not None and plan["ptrs"] == self._refresh_ptrs():
             return plan
@@ -296,7 +298,7 @@ class Engine:
             if op.kind != "conv" or op.expanded is not None or len(op.convs) != 1:
                 continue
             scale = None
-            if op.bn is not None:
+            if op.bn is not None and not op.bn.training:
                 ent = self._fold_bufs.get(id(op))
                 if ent is None:
                     C = op.spec.cout
@@ -336,12 +338,15 @@ class Engine:
         """After an optimiser / EMA step every folded BN vector and every packed weight operand of the network is stale at
         once: rebuild them ALL in two launches (dasac_bn_fold_multi, dasac_conv_pack_multi) instead of one small launch per
         layer and layout as they are first used (~310 launches per student step).  Only when the whole network is stale and
-        runs frozen-BN fp32 -- partial invalidations, batch-statistics BN and the split-bf16 operands keep the per-layer path."""
+        runs fp32 -- partial invalidations and the split-bf16 operands keep the per-layer path.  Convolutions in front of a
+        batch-statistics BN (round 4: cfg-2 spent 1.5 ms per step in 228 per-layer pack launches) are packed un-scaled by the
+        same launch; only frozen BNs have a fold job."""
         if ops.PRECISION != "fp32":
             return
         convs = [op for op in self.plan.ops if op.kind == "conv" and op.expanded is None and len(op.convs) == 1]
-        if len(convs) < 8 or any(op.bn is not None and op.bn.training for op in convs):
+        if len(convs) < 8:
             return
+        frozen = lambda op: op.bn is not None and not op.bn.training
         # stale = the cached key no longer matches the parameters' version counters
         def pack_key(op, scale):
             return (_ver(op.convs[0].weight),) + ((_ver(scale),) if scale is not None else ()) + (ops.PRECISION,)
@@ -351,10 +356,14 @@ class Engine:
             return (_ver(bn.weight), _ver(bn.bias), _ver(bn.running_mean), _ver(bn.running_var), None if cb is None else _ver(cb))
         for op in convs:                                     # all-or-nothing: the first fresh layer ends the check
             ent = self._packs.get((id(op), False))
-            sc = self._folds.get(id(op))
-            fresh_fold = op.bn is None or (sc is not None and sc[0] == fold_key(op))
-            if fresh_fold and ent is not None and ent[0] == pack_key(op, None if op.bn is None else sc[1][0]):
-                return
+            sc = self._folds.get(id(op)) if frozen(op) else None
+            fresh_fold = (not frozen(op)) or (sc is not None and sc[0] == fold_key(op))
+            if fresh_fold and ent is not None and ent[0] == pack_key(op, sc[1][0] if frozen(op) else None):
+                # (the forward layout may have been refreshed alone by a no-grad pass -- AdaBN's target forward right after the
+                # optimiser step: the data-gradient layout is then still stale, and one more launch beats 104 per-layer ones)
+                ent_t = self._packs.get((id(op), True)) if transposed else ent
+                if ent_t is not None and ent_t[0] == ent[0]:
+                    return
         plan = self._refresh_plan(device, transposed)
         ops.refresh_network(plan["tables"])
         for op in plan["fold_ops"]:
@@ -388,10 +397,12 @@ class Engine:
                 if op.bn is not None and op.bn.training:
                     # batch-statistics BN (baseline / AdaBN mode): raw conv, then stats -> normalise(+res)(+ReLU)
                     cb = op.convs[0].bias.detach() if op.has_bias else None
+                    # the GEMM epilogue leaves the per-tile channel sums / sums of squares next to z: no statistics pass over z
+                    ts = ops.tile_stats_buffer(Nb, op.spec.cout, OH, OW, xin.device) if ops.stats_ok(op.spec.cout, op.spec.cin) else None
                     ops.conv_gemm(xin, self.packed(op, False, None), self.table(op, H, W, False, xin.device), out, (OH, OW),
-                                  op.spec.stride, op.spec.cout, op.spec.K, 1, cb, None, None, False)
+                                  op.spec.stride, op.spec.cout, op.spec.K, 1, cb, None, None, False, stats=ts)
                     z = out
-                    out, stats = ops.bn_train_forward(z, op.bn, None if op.res is None else acts[op.res], op.relu)
+                    out, stats = ops.bn_train_forward(z, op.bn, None if op.res is None else acts[op.res], op.relu, tile_stats=ts)
                     if keep:
                         saved["aux"][i] = (z, stats)
                 else:

@@ -185,9 +185,22 @@ class ReluBits:
         self.words = torch.empty(L.load().dasac_relu_bits_words(M, Nb * OH * OW), dtype=torch.int32, device=device)
 
 
-def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=None, res=None, mask=None, relu=False, bits_out=None):
+def stats_ok(M, Cx):
+    """True when the conv GEMM for M output channels over Cx gathered channels can leave per-tile channel statistics."""
+    return PRECISION == "fp32" and os.environ.get("DASAC_GEMM_STATS", "1") != "0" and bool(L.load().dasac_conv_gemm_stats_ok(int(M), int(Cx)))
+
+
+def tile_stats_buffer(Nb, M, OH, OW, device):
+    """[pixel tiles, 2, Mpad] fp32: filled by conv_gemm(stats=...) (every slot written), read by bn_train_forward."""
+    lib = L.load()
+    return torch.empty((lib.dasac_conv_gemm_stats_tiles(Nb, OH, OW), 2, lib.dasac_conv_mpad(M)), dtype=torch.float32, device=device)
+
+
+def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=None, res=None, mask=None, relu=False, bits_out=None,
+              stats=None):
     """out[n,m,oh*os,ow*os] = epilogue(sum_k packed[k][m] * gather(x)); see dasac_conv_gemm.
-    mask: fp32 activation (zero where <= 0) or a ReluBits of the output's shape; bits_out: ReluBits to fill (relu only)."""
+    mask: fp32 activation (zero where <= 0) or a ReluBits of the output's shape; bits_out: ReluBits to fill (relu only);
+    stats: `tile_stats_buffer` to fill with per-tile channel sums / sums of squares of the output (dasac_conv_gemm_stats)."""
     lib = L.load()
     L.require_gpu(x, packed, table, out)
     Nb, Cx, H, W = x.shape
@@ -210,6 +223,14 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
         frac = n / float(Nb * OH * OW)
         nbytes = 4.0 * (x.numel() * frac + packed.numel() + n * M * (1 + (res is not None) + (mask is not None)
                                                                      + ((mask_bits is not None) + (bits_out is not None)) / 32.0))
+        if stats is not None:
+            assert mask is None and mask_bits is None and bits_out is None and stats.is_contiguous() and stats.dtype == torch.float32
+            with PROFILE.span(span, 2.0 * n * M * K, tag, nbytes):
+                L.check(lib.dasac_conv_gemm_stats(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
+                                                  stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res), int(relu),
+                                                  pix_begin, pix_count, schedule, L.ptr(ws), 0 if ws is None else ws.numel(),
+                                                  stats.data_ptr(), L.stream_ptr()), "dasac_conv_gemm_stats")
+            return
         with PROFILE.span(span, 2.0 * n * M * K, tag, nbytes):
             L.check(fn(x.data_ptr(), packed.data_ptr(), table.data_ptr(), out.data_ptr(), Nb, Cx, H, W, OH, OW,
                        stride, M, K, out.shape[2], out.shape[3], ostride, L.ptr(shift), L.ptr(res),
@@ -752,21 +773,33 @@ def _allreduce_sums(sums, count):
     return packed[:-1], 0.0, packed[-1:]
 
 
-def bn_train_forward(z, bn, res=None, relu=False, update_running=True):
-    """y = relu?(BN_batch(z) (+res)); returns (y, (mean, invstd, count, count_dev)).  Updates bn.running_* like ATen."""
+def bn_train_forward(z, bn, res=None, relu=False, update_running=True, tile_stats=None):
+    """y = relu?(BN_batch(z) (+res)); returns (y, (mean, invstd, count, count_dev)).  Updates bn.running_* like ATen.
+    tile_stats: the per-tile channel statistics the producing conv_gemm(stats=...) left -- then z is not read for them."""
     lib = L.load()
-    L.require_gpu(z, res)
+    L.require_gpu(z, res, tile_stats)
     N, Cn = z.shape[0], z.shape[1]
     HW = z[0, 0].numel()
-    sums = _bn_sums(lib.dasac_bn_stats, (z.data_ptr(),), N, Cn, HW, z.device, "dasac_bn_stats")
-    sums, count, count_dev = _allreduce_sums(sums, N * HW)
     scale, shift, mean, invstd = (_f32((Cn,), z) for _ in range(4))
     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
     upd = update_running and bn.track_running_stats
-    L.check(lib.dasac_bn_train_finalize(sums.data_ptr(), count, L.ptr(count_dev), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                        bn.running_mean.data_ptr() if upd else None, bn.running_var.data_ptr() if upd else None,
-                                        bn.num_batches_tracked.data_ptr() if upd else None, float(mom), float(bn.eps), Cn, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                                        invstd.data_ptr(), L.stream_ptr()), "dasac_bn_train_finalize")
+    tail = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr() if upd else None, bn.running_var.data_ptr() if upd else None,
+            bn.num_batches_tracked.data_ptr() if upd else None, float(mom), float(bn.eps), Cn, scale.data_ptr(), shift.data_ptr(),
+            mean.data_ptr(), invstd.data_ptr(), L.stream_ptr())
+    if tile_stats is not None and _world() == 1:
+        # one rank: the finalize kernel adds the tiles itself -- ONE small launch per BN layer, no pass over z
+        count, count_dev = float(N * HW), None
+        L.check(lib.dasac_bn_train_finalize_tiles(tile_stats.data_ptr(), tile_stats.shape[0], tile_stats.shape[2], count, *tail),
+                "dasac_bn_train_finalize_tiles")
+    else:
+        if tile_stats is not None:
+            sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
+            L.check(lib.dasac_bn_tile_stats_reduce(tile_stats.data_ptr(), tile_stats.shape[0], Cn, tile_stats.shape[2], sums.data_ptr(),
+                                                   L.stream_ptr()), "dasac_bn_tile_stats_reduce")
+        else:
+            sums = _bn_sums(lib.dasac_bn_stats, (z.data_ptr(),), N, Cn, HW, z.device, "dasac_bn_stats")
+        sums, count, count_dev = _allreduce_sums(sums, N * HW)
+        L.check(lib.dasac_bn_train_finalize(sums.data_ptr(), count, L.ptr(count_dev), *tail), "dasac_bn_train_finalize")
     if upd:                                                    # written through raw pointers; eval-mode folds key on them
         bump_versions([bn.running_mean, bn.running_var, bn.num_batches_tracked])
     y = torch.empty_like(z)
@@ -783,24 +816,20 @@ def bn_train_backward(dy, z, stats, gamma, want_params=True, outs=(None, None)):
     N, Cn = z.shape[0], z.shape[1]
     HW = z[0, 0].numel()
     dy = _c(dy)
-    sums = _bn_sums(lib.dasac_bn_bwd_reduce, (dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr()), N, Cn, HW, z.device,
-                    "dasac_bn_bwd_reduce")
-    local = sums
-    if _world() > 1:
-        import torch.distributed as dist
-        sums = sums.clone()
-        dist.all_reduce(sums)
-    dz = torch.empty_like(z)
     dg = _dest(outs[0], gamma) if want_params else None
     db = _dest(outs[1], gamma) if want_params else None
-    fused = want_params and sums is local                     # one rank: the kernel writes d gamma / d beta itself
+    # the reduction's finish kernel also writes d gamma / d beta -- this rank's LOCAL sums (DDP averages them afterwards)
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
+    ws = L.workspace(lib.dasac_bn_stats_workspace(N, Cn, HW), z.device)
+    L.check(lib.dasac_bn_bwd_reduce(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), N, Cn, HW, sums.data_ptr(),
+                                    L.ptr(dg), L.ptr(db), ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_bn_bwd_reduce")
+    if _world() > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums)
+    dz = torch.empty_like(z)
     L.check(lib.dasac_bn_bwd_apply(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                   sums.data_ptr(), float(count), L.ptr(count_dev), N, Cn, HW, dz.data_ptr(),
-                                   L.ptr(dg) if fused else None, L.ptr(db) if fused else None, L.stream_ptr()),
+                                   sums.data_ptr(), float(count), L.ptr(count_dev), N, Cn, HW, dz.data_ptr(), None, None, L.stream_ptr()),
             "dasac_bn_bwd_apply")
-    if want_params and not fused:     # parameter gradients are LOCAL sums (DDP averages them across ranks afterwards)
-        dg.copy_(local[Cn:].to(torch.float32))
-        db.copy_(local[:Cn].to(torch.float32))
     return dz, dg, db
 
 

@@ -127,6 +127,21 @@ int dasac_conv_gemm_x3(const float* x, const void* packed_x3, const int32_t* tab
                        const uint32_t* mask_bits, uint32_t* relu_bits_out,
                        int relu, int pix_begin, int pix_count, int schedule,
                        void* workspace, size_t ws_bytes, dasac_stream_t stream);
+/* dasac_conv_gemm (fp32, no residual / mask / bit masks) whose epilogue ALSO leaves the per-channel statistics a
+ * batch-statistics BatchNorm behind the convolution needs (nn.SyncBatchNorm in train mode: deeplabv2.py:15 with
+ * models/__init__.py:29 BASELINE, train.py:281-289): stats [dasac_conv_gemm_stats_tiles(Nb, OH, OW)][2][dasac_conv_mpad(M)]
+ * floats = per 128-pixel tile the sum and the sum of squares of every output row as stored (shift / bias included).  Every
+ * slot is written by exactly one workgroup (also under the stream-K schedule); dasac_bn_train_finalize_tiles /
+ * dasac_bn_tile_stats_reduce add the tiles in a fixed order -- no atomics, run-to-run identical.  Removes the stand-alone
+ * statistics pass over the activation (one full read per BN layer).  Needs dasac_conv_gemm_stats_ok(M, Cx) (the 128-row
+ * tile, Cx % 16 == 0) and ostride = 1. */
+int dasac_conv_gemm_stats_ok(int M, int Cx);
+int dasac_conv_gemm_stats_tiles(int Nb, int OH, int OW);
+int dasac_conv_gemm_stats(const float* x, const float* packed, const int32_t* table, float* out,
+                          int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int K,
+                          int OutH, int OutW, int ostride, const float* shift, const float* res, int relu,
+                          int pix_begin, int pix_count, int schedule, void* workspace, size_t ws_bytes,
+                          float* stats, dasac_stream_t stream);
 size_t dasac_conv_gemm_workspace(void);
 int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K);   /* 1 = stream-K, 0 = one block per tile */
 /* > 0: issue the conv as two launches -- pixels [0, n) with schedule 1, the rest with schedule 0 (see conv_igemm.hip) */
@@ -290,10 +305,19 @@ int dasac_bn_train_finalize(const double* sums, double count, const double* coun
                             int64_t* num_batches_tracked /* += 1 when given */, float momentum, float eps, int C,
                             float* scale, float* shift, float* mean, float* invstd,
                             dasac_stream_t stream);
+/* The same with the statistics left by dasac_conv_gemm_stats: dasac_bn_train_finalize_tiles sums the tiles itself (one launch
+ * per BN layer on one rank); dasac_bn_tile_stats_reduce only produces `sums` (then all-reduce + dasac_bn_train_finalize = SyncBN). */
+int dasac_bn_train_finalize_tiles(const float* tile_stats, int n_tiles, int mpad, double count, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, float momentum, float eps, int C,
+                                  float* scale, float* shift, float* mean, float* invstd, dasac_stream_t stream);
+int dasac_bn_tile_stats_reduce(const float* tile_stats, int n_tiles, int C, int mpad, double* sums, dasac_stream_t stream);
 int dasac_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu,
                    int N, int C, int64_t HW, float* y, dasac_stream_t stream);
 int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd,
-                        int N, int C, int64_t HW, double* sums, void* workspace, size_t ws_bytes, dasac_stream_t stream);
+                        int N, int C, int64_t HW, double* sums, float* dgamma /* optional: this rank's sum dy*xhat */,
+                        float* dbeta /* optional: this rank's sum dy */, void* workspace, size_t ws_bytes,
+                        dasac_stream_t stream);
 int dasac_bn_bwd_apply(const float* dy, const float* z, const float* mean, const float* invstd,
                        const float* gamma, const double* sums, double count, const double* count_dev, int N, int C,
                        int64_t HW, float* dz, float* dgamma, float* dbeta, dasac_stream_t stream);

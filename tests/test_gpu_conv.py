@@ -281,3 +281,52 @@ def test_relu_bit_masks_equal_the_fp32_pattern(cin, cout, k, dil, shape):
         b = ops.conv_dgrad(spec2, dz, [w2], (H, W), res=res, mask=bits)
         assert torch.equal(a, b)
         assert float((a == 0).float().mean()) > 0.2
+
+
+STATS_CASES = [
+    # name, cin, cout, branch, (N,H,W): one block per tile / the persistent stream-K schedule (long K, few tiles: the worker that
+    # holds a tile's first K-steps runs the epilogue and must own the tile's statistics slot) / a ragged last M tile and pixel tile
+    ("tiles_1x1", 64, 256, (1, 1, 1, 0), (2, 25, 33)),
+    ("streamk_3x3", 128, 256, (3, 3, 2, 2), (2, 33, 41)),
+    ("ragged_m200", 128, 200, (3, 3, 2, 2), (3, 9, 13)),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_gemm_epilogue_channel_statistics(case):
+    """dasac_conv_gemm_stats: the raw conv (+ bias) in front of a batch-statistics BatchNorm (deeplabv2.py:15 in baseline mode)
+    also leaves per-tile channel sums / sums of squares.  Output bit-equal to the plain kernel's; statistics against float64
+    sums of that output; two runs bit-identical (every slot has one writer); and bn_train_forward on them equals the
+    stand-alone statistics pass."""
+    import torch.nn as nn
+    from dasac_hip import ops
+    name, cin, cout, br, (N, H, W) = case
+    spec = ops.ConvSpec(cin, cout, [br], 1)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(N, cin, H, W, generator=g) + 0.3).cuda()
+    w = (torch.randn(cout, cin, br[0], br[1], generator=g) / (cin * br[0] * br[1]) ** 0.5).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    assert ops.stats_ok(cout, cin)
+    order = ops.gemm_order(spec, False)
+    table, packed = ops.conv_table(spec, H, W, False, x.device, order), ops.conv_pack(spec, [w], False, None, order=order)
+    OH, OW = spec.out_hw(H, W)
+    plain = torch.empty((N, cout, OH, OW), device="cuda")
+    ops.conv_gemm(x, packed, table, plain, (OH, OW), 1, cout, spec.K, 1, bias)
+    runs = []
+    for _ in range(2):
+        out = torch.empty_like(plain)
+        ts = ops.tile_stats_buffer(N, cout, OH, OW, x.device).fill_(float("nan"))
+        ops.conv_gemm(x, packed, table, out, (OH, OW), 1, cout, spec.K, 1, bias, stats=ts)
+        runs.append((out, ts))
+    (out, ts), (out2, ts2) = runs
+    assert torch.equal(out, plain) and torch.equal(out2, plain) and torch.equal(ts, ts2)
+    assert not torch.isnan(ts).any() and float(ts[:, :, cout:].abs().max() if ts.shape[2] > cout else 0.0) == 0.0
+    s, q = ts[:, 0, :cout].double().sum(0), ts[:, 1, :cout].double().sum(0)
+    od = out.double()
+    assert float((s - od.sum((0, 2, 3))).abs().max()) <= 1e-6 * float(od.abs().sum((0, 2, 3)).max())
+    assert float(((q - (od * od).sum((0, 2, 3))) / (od * od).sum((0, 2, 3))).abs().max()) <= 1e-6
+    bn_a, bn_b = nn.BatchNorm2d(cout).cuda(), nn.BatchNorm2d(cout).cuda()
+    ya, (mean_a, inv_a, _, _) = ops.bn_train_forward(out, bn_a, None, True, tile_stats=ts)
+    yb, (mean_b, inv_b, _, _) = ops.bn_train_forward(out, bn_b, None, True)
+    assert rel_err(mean_a, mean_b) < 1e-6 and rel_err(inv_a, inv_b) < 1e-6 and rel_err(ya, yb) < 1e-5
+    assert rel_err(bn_a.running_var, bn_b.running_var) < 1e-6 and int(bn_a.num_batches_tracked) == 1
