@@ -11,6 +11,7 @@
 //   class_state        models/sac.py:104-117,120,151-152                  running class prior, discount, focal weights
 #include "common.hpp"
 
+#include <algorithm>
 #include <atomic>
 
 namespace dasac {
@@ -259,7 +260,7 @@ __device__ __forceinline__ float weight_to(int dst, float scale, int n_in, int t
   if (t.i1 == target) wgt += t.w1;   // i0 == i1 at the border: both weights land on the same source
   return wgt;
 }
-__device__ __forceinline__ void src_range(int target, float scale, int n_out, int& lo, int& hi) {
+__host__ __device__ __forceinline__ void src_range(int target, float scale, int n_out, int& lo, int& hi) {
   // high-res positions whose taps can touch `target`:  target-1 < scale*dst < target+1
   if (scale <= 0.f) {
     lo = 0;
@@ -452,21 +453,32 @@ __global__ void ce_finish(const double* __restrict__ partial, int n, float* __re
 // and upsample_bwd_y finishes with the vertical taps.  LDS index x + x/8 spreads the stride-8 phase-2 reads over all banks.
 __host__ __device__ __forceinline__ int ce_lds_index(int x) { return x + (x >> 3); }
 
+// Round 4: a block handles a SEGMENT of `seg_cols` low-resolution columns of one high-res row (the x range their taps touch,
+// a few hundred pixels) instead of the whole row: 19 x ~300 floats of LDS instead of 19 x 867 (66 KB, two blocks per CU whose
+// two serial phases rarely overlapped) -- six 128-thread blocks per CU, phases of different blocks overlap.  The pixels between
+// two segments' column ranges are evaluated by both (softmax is per pixel: same bits); every column is summed by ONE block over
+// ascending x exactly as before, so the result stays bit-identical to dasac_ce_loss(dlogits) + dasac_upsample_bwd.
+constexpr int kCB = 128;
 template <int CT>
-__global__ __launch_bounds__(kHB) void ce_bwd_rows(const float* __restrict__ xup, const int64_t* __restrict__ y,
+__global__ __launch_bounds__(kCB) void ce_bwd_rows(const float* __restrict__ xup, const int64_t* __restrict__ y,
                                                   const float* __restrict__ cw, const float* __restrict__ conf, int B, int Crt,
                                                   int H, int W, int w, float sw, int mode, const float* __restrict__ gscale,
-                                                  float* __restrict__ tmp) {
+                                                  float* __restrict__ tmp, int seg_cols, int n_seg, int pitch) {
   extern __shared__ float s_d[];                      // [C][pitch]
   const int C = CT < kMaxC ? CT : Crt;
-  const int pitch = ce_lds_index(W - 1) + 2;
-  const int b = blockIdx.x / H, oy = blockIdx.x - b * H;
+  const int seg = blockIdx.x % n_seg, rowid = blockIdx.x / n_seg;
+  const int b = rowid / H, oy = rowid - b * H;
+  const int j0 = seg * seg_cols, j1 = min(w, j0 + seg_cols);
+  int xs, xe, dummy;
+  src_range(j0, sw, W, xs, dummy);
+  src_range(j1 - 1, sw, W, dummy, xe);
+  xs &= ~3;                                           // quads start on the same grid for every segment
   const int HW = H * W;
   const float gs = gscale ? gscale[0] : 1.f;
   const float norm = mode == 1 ? 1.f / ((float)B * (float)B * (float)HW) : 1.f / ((float)B * (float)HW);
   // phase 1: four consecutive pixels per thread -- every class plane is ONE (4-byte aligned) dwordx4 load and all CT of
   // them are in flight together (compile-time class count: no per-class predicate between the loads)
-  for (int ox = threadIdx.x * 4; ox < W; ox += kHB * 4) {
+  for (int ox = xs + threadIdx.x * 4; ox <= xe; ox += kCB * 4) {
     const int nx = min(4, W - ox);
     const int p = oy * W + ox;
     const size_t base = (size_t)b * C * HW + p;
@@ -538,16 +550,17 @@ __global__ __launch_bounds__(kHB) void ce_bwd_rows(const float* __restrict__ xup
       if (c < C) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (e < nx) s_d[c * pitch + ce_lds_index(ox + e)] = k[e] * v[c][e] - ((c == lab[e]) ? gw[e] : 0.f);
+          if (e < nx) s_d[c * pitch + ce_lds_index(ox + e - xs)] = k[e] * v[c][e] - ((c == lab[e]) ? gw[e] : 0.f);
       }
   }
   __syncthreads();
   // phase 2: thread -> (column j, class group).  The tap weights of column j are computed once (registers) and reused
   // for every class of the group; the sum runs over ascending x like upsample_bwd_x does.
   constexpr int kMaxSpan = 24;                           // 2/scale + 3 taps: covers up-factors to 10
-  const int groups = max(1, min(C, kHB / max(w, 1)));
-  for (int o = threadIdx.x; o < w * groups; o += kHB) {
-    const int j = o % w, g0 = o / w;
+  const int nj = j1 - j0;
+  const int groups = max(1, min(C, kCB / max(nj, 1)));
+  for (int o = threadIdx.x; o < nj * groups; o += kCB) {
+    const int j = j0 + o % nj, g0 = o / nj;
     int lo, hi;
     src_range(j, sw, W, lo, hi);
     const int n = hi - lo + 1;
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(kHB) void ce_bwd_rows(const float* __restrict__ xup
 #pragma unroll
       for (int i = 0; i < kMaxSpan; ++i) {
         wt[i] = i < n ? weight_to(lo + i, sw, w, j) : 0.f;
-        li[i] = ce_lds_index(min(lo + i, W - 1));
+        li[i] = ce_lds_index(min(lo + i, W - 1) - xs);
       }
       for (int c = g0; c < C; c += groups) {
         const float* row = s_d + c * pitch;
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(kHB) void ce_bwd_rows(const float* __restrict__ xup
     } else {
       for (int c = g0; c < C; c += groups) {
         float acc = 0.f;
-        for (int xx = lo; xx <= hi; ++xx) acc += weight_to(xx, sw, w, j) * s_d[c * pitch + ce_lds_index(xx)];
+        for (int xx = lo; xx <= hi; ++xx) acc += weight_to(xx, sw, w, j) * s_d[c * pitch + ce_lds_index(xx - xs)];
         tmp[((size_t)(b * C + c) * H + oy) * w + j] = acc;
       }
     }
@@ -761,25 +774,8 @@ __global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ p
 }
 
 // refined[b] = sample(pooled[g(b)], theta_inv[b]) * sample(mask[g(b)], theta_inv[b]),  g(b) = group_of[b]
-// CT > 0: compile-time class count -- the class loop is unrolled and all 4*CT taps of a pixel are independent loads in flight
-template <int CT>
-__global__ __launch_bounds__(kHB) void warp_back_ct(const float* __restrict__ pooled, const float* __restrict__ mask,
-                                                    const float* __restrict__ theta_inv, int group_div, int H, int W,
-                                                    float* __restrict__ refined, int blocks_per_image) {
-  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
-  const int n = b / group_div;
-  const int HW = H * W;
-  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
-    const Sample s = make_sample(theta_inv + b * 6, p / W, p % W, H, W);
-    const float mv = take(mask + (size_t)n * HW, s);
-    float v[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) v[c] = take(pooled + ((size_t)n * CT + c) * HW, s);
-#pragma unroll
-    for (int c = 0; c < CT; ++c) refined[((size_t)b * CT + c) * HW + p] = v[c] * mv;
-  }
-}
-
+// (round 4, measured: a compile-time class count with all 4 x 19 taps of a pixel in flight makes this kernel SLOWER -- 327 vs
+// 213 us at 8 x 19 x 769^2: the registers of 76 gathers in flight cost more occupancy than the batching wins; the class loop stays)
 __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ pooled, const float* __restrict__ mask,
                                                  const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
                                                  float* __restrict__ refined, int blocks_per_image) {
@@ -929,8 +925,24 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
                     (mode == 0 || (mode == 1 && conf)),
                 "ce_loss_bwd_low: bad arguments");
   if (ws_bytes < dasac_ce_loss_bwd_low_workspace(B, C, H, w)) return fail(DASAC_EWORKSPACE, "ce_loss_bwd_low: workspace too small");
-  const size_t lds = (size_t)C * (ce_lds_index(W - 1) + 2) * sizeof(float);
-  DASAC_REQUIRE(lds <= 160 * 1024, "ce_loss_bwd_low: a row of C x W gradients does not fit LDS");
+  // segments of low-resolution columns per block: the x range of a segment (+ the taps' reach on both sides) bounds the LDS
+  // row; ~300 pixels (about 24 KB for 19 classes) lets six blocks share a CU
+  const float sw = ac_scale(w, W);
+  int seg_cols = w;
+  if (sw > 0.f) seg_cols = (int)(300.f * sw) - 2;
+  seg_cols = seg_cols < 4 ? 4 : (seg_cols > w ? w : seg_cols);
+  const int n_seg = (w + seg_cols - 1) / seg_cols;
+  int span = 0;
+  for (int sg = 0; sg < n_seg; ++sg) {
+    int xs, xe, dummy;
+    src_range(sg * seg_cols, sw, W, xs, dummy);
+    src_range(std::min(w, (sg + 1) * seg_cols) - 1, sw, W, dummy, xe);
+    xs &= ~3;
+    span = std::max(span, (xe | 3) + 1 - xs);              // whole quads
+  }
+  const int pitch = ce_lds_index(span - 1) + 2;
+  const size_t lds = (size_t)C * pitch * sizeof(float);
+  DASAC_REQUIRE(lds <= 160 * 1024, "ce_loss_bwd_low: a segment of C x W gradients does not fit LDS");
   hipStream_t s = as_stream(stream);
   float* tmp = reinterpret_cast<float*>(workspace);
   if (lds > 64 * 1024) {                                 // raise the kernels' dynamic-LDS limit once per device, not per launch
@@ -944,12 +956,13 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
       raised.fetch_or(bit, std::memory_order_relaxed);
     }
   }
+  DASAC_REQUIRE((int64_t)B * H * n_seg < (1ll << 31), "ce_loss_bwd_low: grid too large");
   if (C == 19)
-    hipLaunchKernelGGL(ce_bwd_rows<19>, dim3(B * H), dim3(kHB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
-                       ac_scale(w, W), mode, gscale, tmp);
+    hipLaunchKernelGGL(ce_bwd_rows<19>, dim3(B * H * n_seg), dim3(kCB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
+                       sw, mode, gscale, tmp, seg_cols, n_seg, pitch);
   else
-    hipLaunchKernelGGL(ce_bwd_rows<kMaxC>, dim3(B * H), dim3(kHB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
-                       ac_scale(w, W), mode, gscale, tmp);
+    hipLaunchKernelGGL(ce_bwd_rows<kMaxC>, dim3(B * H * n_seg), dim3(kCB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
+                       sw, mode, gscale, tmp, seg_cols, n_seg, pitch);
   DASAC_CHECK_LAUNCH("ce_bwd_rows");
   const int64_t t2 = (int64_t)B * C * h * w;
   hipLaunchKernelGGL(upsample_bwd_y, dim3(stream_grid(t2, kHB)), dim3(kHB), 0, s, tmp, H, h, w, ac_scale(h, H), nullptr, grad_low, t2);
@@ -989,12 +1002,8 @@ extern "C" int dasac_warp_back(const float* pooled, const float* mask, const flo
                                int C, int H, int W, float* refined, dasac_stream_t stream) {
   DASAC_REQUIRE(pooled && mask && theta_inv && refined && B > 0 && views_per_group > 0, "warp_back: bad arguments");
   const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
-  if (C == 19)
-    hipLaunchKernelGGL(warp_back_ct<19>, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, H, W,
-                       refined, per);
-  else
-    hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
-                       W, refined, per);
+  hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
+                     W, refined, per);
   DASAC_CHECK_LAUNCH("warp_back");
   return DASAC_OK;
 }

@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256) void channel_sums(const float* __restrict__ x,
 // forward also records the argmax position inside the window (kh*k + kw), first maximum wins.
 // KT / ST: compile-time window and stride (0 = take the runtime values): the 3x3/2 stem pool and the 2x2/2, 3x3/1 VGG pools
 // get unrolled windows and no integer division by a runtime value; all index math is 32-bit (total < 2^31, checked by the host).
+// argmax byte: bits 0-6 = position inside the window (kh*k + kw), bit 7 = (pooled value > 0) for windows up to 11 x 11 -- the
+// backward pass with the producer's ReLU folded in (`relu_mask`) then needs no read of the pooled tensor (a third of its bytes)
+constexpr int kPoolSignMaxK = 11;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int KT, int ST>
 __global__ __launch_bounds__(256) void maxpool_fwd(const float* __restrict__ x, int H, int W, int OH, int OW, int k_rt, int s_rt,
                                                    int pad, float* __restrict__ y, uint8_t* __restrict__ arg, int total) {
@@ -104,15 +109,77 @@ __global__ __launch_bounds__(256) void maxpool_fwd(const float* __restrict__ x, 
       }
     }
     y[i] = best;
-    arg[i] = (uint8_t)code;
+    arg[i] = (uint8_t)(code | ((k <= kPoolSignMaxK && best > 0.f) ? 0x80 : 0));
+  }
+}
+
+// The 3x3 / stride-2 stem pool (deeplabv2.py:126) and the 2x2 / 2 VGG pools with FOUR horizontally adjacent outputs per thread:
+// the 3*ST + KT input columns under them are read once per window row as two dwordx4 + (KT + 3*ST - 8) scalars (9 load
+// instructions per 4 outputs for 3x3/2 where the one-output kernel issues 36 dword loads), y leaves as one dwordx4.  Same scan
+// order per output (rows outer, columns inner, first maximum wins, NaN propagates): identical y and argmax codes.
+template <int KT, int ST>
+__global__ __launch_bounds__(256) void maxpool_fwd_quad(const float* __restrict__ x, int H, int W, int OH, int OW, int pad,
+                                                        float* __restrict__ y, uint8_t* __restrict__ arg, int items) {
+  constexpr int NCOL = 3 * ST + KT;
+  static_assert(NCOL >= 8 && NCOL <= 12, "maxpool_fwd_quad: two dwordx4 loads + up to four scalars per window row");
+  const int OWq = (OW + 3) >> 2;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int q = it % OWq, r = it / OWq;
+    const int oh = r % OH, plane = r / OH;
+    const int ow0 = q * 4, nx = min(4, OW - ow0);
+    const float* xp = x + (size_t)plane * H * W;
+    const int ih0 = oh * ST - pad, iw0 = ow0 * ST - pad;
+    const bool inner = iw0 >= 0 && iw0 + NCOL <= W;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int code[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < KT; ++a) {
+      const int ih = ih0 + a;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      const float* row = xp + ih * W + iw0;
+      float v[NCOL];
+      if (inner) {
+        const f32x4u v0 = *reinterpret_cast<const f32x4u*>(row), v1 = *reinterpret_cast<const f32x4u*>(row + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = v0[c];
+          v[4 + c] = v1[c];
+        }
+#pragma unroll
+        for (int c = 8; c < NCOL; ++c) v[c] = row[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) v[c] = (unsigned)(iw0 + c) < (unsigned)W ? row[c] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < KT; ++b) {
+          const int c = e * ST + b;
+          const float val = v[c];
+          if ((inner || (unsigned)(iw0 + c) < (unsigned)W) && (val > best[e] || val != val)) {
+            best[e] = val;
+            code[e] = a * KT + b;
+          }
+        }
+    }
+    const size_t o = ((size_t)plane * OH + oh) * OW + ow0;
+    if (nx == 4) {
+      *reinterpret_cast<f32x4u*>(y + o) = f32x4u{best[0], best[1], best[2], best[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (e < nx) y[o + e] = best[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < nx) arg[o + e] = (uint8_t)(code[e] | (best[e] > 0.f ? 0x80 : 0));
   }
 }
 
 // dx[ih,iw] = sum over windows o containing (ih,iw) with argmax(o) == this position of dy(o)
 // relu_mask: additionally require y(o) > 0 -- the pooled tensor is ReLU output, so this is exactly
 // the ReLU backward of the producer folded in (no need to keep the un-pooled activation).
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-
 // Four consecutive input pixels of one row per thread: the (at most 2 x 3 for the 3x3/2 stem pool) windows that can
 // have picked any of them are read ONCE (argmax code, pooled value, gradient) and each routes its gradient to the
 // pixel its code names -- a scatter inside the thread's registers, no atomics; one dwordx4 store.  32-bit index math.
@@ -145,9 +212,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy,
 #pragma unroll
         for (int b = 0; b < NC; ++b) {
           const size_t o = ob + (size_t)min(oh_lo + a, OH - 1) * OW + min(ow_lo + b, OW - 1);
-          code[a][b] = arg[o];
+          const int ab = arg[o];
+          code[a][b] = ab & 0x7f;
           dv[a][b] = dy[o];
-          yv[a][b] = relu_mask ? y[o] : 1.f;
+          yv[a][b] = !relu_mask ? 1.f : (KT <= kPoolSignMaxK ? (float)(ab >> 7) : y[o]);    // bit 7: pooled value > 0
         }
 #pragma unroll
       for (int a = 0; a < NR; ++a)
@@ -167,9 +235,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy,
     for (int oh = oh_lo; oh <= oh_hi; ++oh)
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
         const size_t o = ob + (size_t)oh * OW + ow;
-        const int code = arg[o];
+        const int ab = arg[o];
+        const int code = k <= kPoolSignMaxK ? (ab & 0x7f) : ab;
         const int r = oh * s - pad + code / k, c = ow * s - pad + code % k - iw0;
-        if (r == ih && (unsigned)c < 4u && (!relu_mask || y[o] > 0.f)) {
+        if (r == ih && (unsigned)c < 4u && (!relu_mask || (k <= kPoolSignMaxK ? (ab >> 7) != 0 : y[o] > 0.f))) {
           const float d = dy[o];
           g[0] += c == 0 ? d : 0.f;
           g[1] += c == 1 ? d : 0.f;
@@ -354,8 +423,10 @@ extern "C" int dasac_maxpool_fwd(const float* x, int planes, int H, int W, int O
   DASAC_REQUIRE(total < (1ll << 31), "maxpool_fwd: tensor too large");
   const dim3 grid(stream_grid(total, 256));
   hipStream_t st = as_stream(stream);
-  if (k == 3 && s == 2) hipLaunchKernelGGL((maxpool_fwd<3, 2>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
-  else if (k == 2 && s == 2) hipLaunchKernelGGL((maxpool_fwd<2, 2>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
+  const int items4 = planes * OH * ((OW + 3) / 4);
+  const dim3 grid4(stream_grid(items4, 256));
+  if (k == 3 && s == 2) hipLaunchKernelGGL((maxpool_fwd_quad<3, 2>), grid4, dim3(256), 0, st, x, H, W, OH, OW, pad, y, argmax, items4);
+  else if (k == 2 && s == 2) hipLaunchKernelGGL((maxpool_fwd_quad<2, 2>), grid4, dim3(256), 0, st, x, H, W, OH, OW, pad, y, argmax, items4);
   else if (k == 3 && s == 1) hipLaunchKernelGGL((maxpool_fwd<3, 1>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
   else hipLaunchKernelGGL((maxpool_fwd<0, 0>), grid, dim3(256), 0, st, x, H, W, OH, OW, k, s, pad, y, argmax, (int)total);
   DASAC_CHECK_LAUNCH("maxpool_fwd");

@@ -246,7 +246,9 @@ int dasac_class_state(float* running_conf, const double* class_sums, int B, int6
  *     sum_rows dot[row][c] = sum dz*conv(x) (the `dot_rows` partial rows of dasac_conv_wgrad_finish) and sum_dz[c]
  *     (dasac_channel_sums or the wgrad kernel).
  * dasac_maxpool_fwd/bwd  nn.MaxPool2d (deeplabv2.py:126 ceil_mode 3x3/2; VGG 2x2/2); caller passes
- *     the resolved OH/OW.  bwd with relu_mask folds the ReLU backward of the producer.
+ *     the resolved OH/OW.  bwd with relu_mask folds the ReLU backward of the producer.  `argmax` is an opaque byte per
+ *     output handed from fwd to bwd: bits 0-6 the winning position kh*k + kw, bit 7 (windows up to 11x11) = pooled value > 0,
+ *     so that the ReLU-folding backward does not read the pooled tensor (`y` is then unused; larger windows do read it).
  * dasac_ema_update       momentum teacher (sac.py:83-102) over all tensors in one launch:
  *     out[0] = sum_t ||slow_t - fast_t||_2 (before the update); slow = slow*m + fast*(1-m).
  *     `pairs`: device array of {const float* fast; float* slow; int64 n}; `chunks`: device (tensor, chunk) int32 pairs of

@@ -179,3 +179,53 @@ def test_gradient_sink_layout_covers_every_trainable_parameter_in_backward_order
         assert hi == lo
     sizes = [(hi - lo) * 4 for lo, hi, _ in sink._buckets]
     assert sizes[0] < 32 << 20 and max(sizes) < 48 << 20 and len(sizes) >= 5
+
+
+def test_gradient_sink_clears_only_the_slices_nobody_wrote():
+    """when a bucket still waits for a member at the end of a backward pass (an op that got no gradient),
+    `finish` must clear THAT member's slice only -- the other members of the bucket were already written and handed to
+    autograd as views.  Also: every bucket is reduced exactly once per pass, and the layout cache follows the engine OBJECT
+    (a rebuilt engine with a recycled id() must not reuse another plan's offsets).  Host logic only."""
+    from dasac_hip.parallel import GradSink
+
+    class FakeOp:
+        def __init__(self, pidx):
+            self.pidx = pidx
+
+    def fake_engine(shapes, groups):
+        return NS(params=[torch.zeros(s) for s in shapes], plan=NS(ops=[FakeOp(g) for g in groups]))
+
+    eng = fake_engine([(4, 3), (5,), (2, 2), (7,)], [[0, 1], [2], [3]])
+    sink = GradSink(bucket_bytes=1 << 30)                     # everything in one bucket
+    need = [True, True, True, True]
+    g = torch.ones(1, 1, 2, 2)
+    sink.begin(eng, need, g)
+    assert len(sink._buckets) == 1
+    views = {j: sink.alloc(j) for j in range(4)}
+    for j in (3, 2, 0):                                       # parameter 1 never gets a gradient in this pass
+        views[j].fill_(float(j + 1))
+    sink.done([3])
+    sink.done([2])
+    sink.done([0])
+    views[1].fill_(float("nan"))                              # whatever the allocator left there
+    sink.finish()
+    assert torch.equal(views[0], torch.full((4, 3), 1.0)) and torch.equal(views[2], torch.full((2, 2), 3.0))
+    assert torch.equal(views[3], torch.full((7,), 4.0)) and torch.equal(views[1], torch.zeros(5))
+    assert sink._launches == [1]
+    # a second pass where everything is written: nothing is cleared, done() twice for one parameter counts once
+    sink.begin(eng, need, g)
+    views = {j: sink.alloc(j) for j in range(4)}
+    for j in range(4):
+        views[j].fill_(7.0)
+    sink.done([3, 3])
+    assert sink._pending[0] == 3
+    sink.done([2, 0, 1])
+    assert sink._launches == [1] and sink._pending[0] == -1
+    sink.finish()
+    assert all(torch.equal(views[j], torch.full_like(views[j], 7.0)) for j in range(4))
+    # another engine object (different plan, possibly the same id() after a rebuild): the layout is rebuilt
+    eng2 = fake_engine([(3,), (6, 2)], [[0], [1]])
+    sink.begin(eng2, [True, True], g)
+    assert set(sink._offsets) == {0, 1} and tuple(sink.alloc(1).shape) == (6, 2)
+    sink.done([1, 0])
+    sink.finish()

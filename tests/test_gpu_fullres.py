@@ -38,6 +38,25 @@ def test_cfg3_resolution_sample_matches_the_oracle(fuse):
     assert cmp_["param_max_err_over_tensor_max"] <= 1e-5
 
 
+def test_cfg3_resolution_sample_is_bit_reproducible():
+    """Round 4: no floating-point atomics are left on the path, the stream-K ranges and the weight-gradient splits are functions
+    of the shape alone -- two runs of the full-resolution sample (769 x 769: student forward / backward, teacher, SAC head, SGD
+    step) from the same state end in the SAME bits: losses, label map, class prior, gradients, parameters."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    if "s" not in _SAMPLE:
+        _SAMPLE["s"] = bench.cpu_sample(769)
+    sd = _SAMPLE["s"][2]
+    dev = torch.device("cuda", 0)
+    a, b = bench.hip_sample(769, sd, dev, fuse=True), bench.hip_sample(769, sd, dev, fuse=True)
+    assert a["loss_ce"] == b["loss_ce"] and a["self_ce"] == b["self_ce"] and a["teacher_diff"] == b["teacher_diff"]
+    assert torch.equal(a["labels"], b["labels"]) and torch.equal(a["running_conf"], b["running_conf"])
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), k
+        assert torch.equal(a["params"][k], b["params"][k]), k
+
+
 def test_full_resolution_head_parity_eight_crops_four_views():
     """VERDICT r3 missing 4: the multi-view head at cfg-3's size with B = 8 crops and L = 4 views per group -- the T = 4 fusion
     of models/sac.py:238-269,289-311 and the [B,B,H,W] broadcast of :148 -- against oracle.head_ref at 769 x 769 (head only, so

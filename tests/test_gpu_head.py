@@ -130,17 +130,30 @@ def test_maxpool_and_relu_masked_backward():
     from dasac_hip import ops
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(3)
-    for (k, s, p, ceil, Hh, W) in ((3, 2, 1, True, 33, 41), (2, 2, 0, False, 16, 24), (3, 2, 1, True, 32, 32)):
+    # 3x3/2 ceil (the stem pool, deeplabv2.py:126) and 2x2/2 (VGG) take the four-outputs-per-thread kernel: widths that are / are
+    # not multiples of 4 outputs, a window row and column hanging over the border (ceil mode), tiny planes; 3x3/1 and 5x5/3 the
+    # one-output kernel
+    for (k, s, p, ceil, Hh, W) in ((3, 2, 1, True, 33, 41), (2, 2, 0, False, 16, 24), (3, 2, 1, True, 32, 32), (3, 2, 1, True, 7, 5),
+                                   (3, 2, 1, True, 65, 130), (2, 2, 0, False, 9, 11), (3, 1, 1, False, 12, 13), (5, 3, 2, True, 21, 23)):
         x = F.relu(torch.randn(2, 5, Hh, W, generator=g)).requires_grad_(True)
-        y = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+        y, idx = F.max_pool2d(x, k, s, p, ceil_mode=ceil, return_indices=True)
         dy = torch.randn(y.shape, generator=g)
         y.backward(dy)
         yy, arg = ops.maxpool_fwd(x.detach().cuda(), k, s, p, ceil)
-        assert torch.equal(yy.cpu(), y.detach())
+        assert torch.equal(yy.cpu(), y.detach()), (k, s, Hh, W)
+        # the argmax byte: window position in bits 0-6 (first maximum wins, like ATen's indices), bit 7 = pooled value > 0
+        code = (arg.cpu() & 0x7f).long()
+        oh = torch.arange(y.shape[2]).view(1, 1, -1, 1)
+        ow = torch.arange(y.shape[3]).view(1, 1, 1, -1)
+        flat = (oh * s - p + code // k) * W + (ow * s - p + code % k)
+        assert torch.equal(torch.gather(x.detach().flatten(2), 2, flat.flatten(2)), y.detach().flatten(2)), (k, s, Hh, W)
+        assert torch.equal((arg.cpu() >> 7).bool(), y.detach() > 0)
         dx = ops.maxpool_bwd(dy.cuda(), yy, arg, (Hh, W), k, s, p, relu_mask=True)
         # oracle: maxpool backward followed by the ReLU backward of the producer (grad * (x>0))
         ref = x.grad * (x.detach() > 0)
-        assert rel_err(dx, ref) < TOL
+        assert rel_err(dx, ref) < TOL, (k, s, Hh, W)
+        dx0 = ops.maxpool_bwd(dy.cuda(), yy, arg, (Hh, W), k, s, p, relu_mask=False)
+        assert rel_err(dx0, x.grad) < TOL, (k, s, Hh, W)
 
 
 def test_bn_fold_channel_sums_ema():

@@ -86,6 +86,27 @@ def test_stepping_through_the_wrapper_matches_the_plain_driver():
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12, k
 
 
+def test_wrapper_refuses_trainable_parameters_it_would_never_reduce():
+    """stock DDP reduces whatever requires grad; this wrapper only what the engine plans differentiate.  A trainable
+    parameter outside every plan must raise at the first forward instead of silently diverging between ranks -- also when the
+    `requires_grad` flip happens after construction."""
+    import driver
+    from dasac_hip.parallel import OverlappedDataParallel
+    src, _ = driver.synthetic_batches(1, 1, 2, (33, 49), "cuda", seed=8)
+    cfg, net = _build()
+    wrapped = OverlappedDataParallel(net, device_ids=[0])
+    wrapped(*src)                                              # engines are captured, coverage verified: fine
+    net.extra_head = nn.Conv2d(19, 19, 1).cuda()              # a trainable layer no engine plan knows about
+    with pytest.raises(RuntimeError, match="extra_head"):
+        wrapped(*src)
+    for p in net.extra_head.parameters():
+        p.requires_grad = False
+    wrapped(*src)                                              # frozen: nothing to reduce, accepted again
+    net.extra_head.weight.requires_grad = True                # flipped back after construction: caught at the next forward
+    with pytest.raises(RuntimeError, match="extra_head.weight"):
+        wrapped(*src)
+
+
 def _rank_main(rank, world, port, q, use_torch_ddp):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

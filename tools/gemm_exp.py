@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "da-sac_amd"))
 import torch
 from dasac_hip import ops
 
-B, H, W = 8, 97, 97
+B, H, W = int(os.environ.get("DASAC_EXP_B", "8")), 97, 97
 SHAPES = [  # name, cin, cout, branch, with residual epilogue
     ("1x1_256_1024+res", 256, 1024, (1, 1, 1, 0), True),
     ("1x1_1024_256", 1024, 256, (1, 1, 1, 0), False),
