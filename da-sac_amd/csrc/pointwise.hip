@@ -639,6 +639,123 @@ __global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ z, con
   }
 }
 
+// One rank (no all-reduce between statistics and normalisation): finalize + apply in ONE launch.  A block owns a 16K-element chunk
+// of one (n, c) plane; it first adds its channel's tile statistics (dasac_conv_gemm_stats) -- 256 threads stride over the tiles,
+// wave butterflies, the four wave sums added in a fixed order: every block of a channel gets the same bits -- derives scale /
+// shift exactly as bn_train_finalize does, normalises its chunk with 16-byte accesses; the block of (n = 0, chunk 0) also writes
+// mean / invstd (for the backward pass) and moves the running statistics.  Saves a 5 us launch per BN layer and pass.
+constexpr int kBnBig = 256 * 64;
+__global__ __launch_bounds__(256) void bn_apply_tiles(const float* __restrict__ z, const float* __restrict__ ts, int n_tiles, int Mpad,
+                                                      double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                      int64_t* __restrict__ num_batches_tracked, float momentum, float eps,
+                                                      const float* __restrict__ res, int relu, int C, int HW,
+                                                      float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int plane = blockIdx.y, c = plane % C, n = plane / C;
+  double s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < n_tiles; i += 256) {
+    s1 += (double)ts[(size_t)(2 * i) * Mpad + c];
+    s2 += (double)ts[(size_t)(2 * i + 1) * Mpad + c];
+  }
+  __shared__ double r1[4], r2[4];
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    r1[threadIdx.x >> 6] = s1;
+    r2[threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  s1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+  s2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0) var = 0;
+  const float meanf = (float)m, varf = (float)var;
+  const float is = 1.f / sqrtf(varf + eps);
+  const float a = gamma[c] * is;
+  const float sh = beta[c] - meanf * a;
+  if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    mean_out[c] = meanf;
+    invstd_out[c] = is;
+    if (running_mean) {
+      const float unbiased = count > 1 ? (float)(var * count / (count - 1)) : varf;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+  }
+  const size_t pb = (size_t)plane * HW;
+  const int lo = blockIdx.x * kBnBig, hi = min(HW, lo + kBnBig);
+  for (int i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+    if (i + 4 <= hi) {
+      f32x4u v = *reinterpret_cast<const f32x4u*>(z + pb + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * a + sh;
+      if (res) {
+        const f32x4u rv = *reinterpret_cast<const f32x4u*>(res + pb + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      *reinterpret_cast<f32x4u*>(y + pb + i) = v;
+    } else {
+      for (int e = i; e < hi; ++e) {
+        float v = z[pb + e] * a + sh;
+        if (res) v += res[pb + e];
+        if (relu) v = fmaxf(v, 0.f);
+        y[pb + e] = v;
+      }
+    }
+  }
+}
+
+// The backward twin: a block adds its channel's (plane, chunk) partial pairs of bn_bwd_reduce itself (N * chunks of them, fixed
+// order, the same in every block), forms dz for a 16K-element chunk of one plane, and the block of (n = 0, chunk 0) writes
+// d gamma / d beta -- no separate finish / parameter launches on one rank.
+__global__ __launch_bounds__(256) void bn_bwd_apply_partials(const float* __restrict__ dy, const float* __restrict__ z,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const double* __restrict__ partial,
+                                                             int N, int chunks_r, double count, int C, int HW,
+                                                             float* __restrict__ dz, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+  const int plane = blockIdx.y, c = plane % C, n = plane / C;
+  double s = 0, q = 0;
+  for (int j = 0; j < N * chunks_r; ++j) {
+    const int nn = j / chunks_r, k = j - nn * chunks_r;
+    const double* o = partial + ((size_t)(nn * C + c) * chunks_r + k) * 2;
+    s += o[0];
+    q += o[1];
+  }
+  if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+  }
+  const float is = invstd[c], mu = mean[c];
+  const float a = (float)(s / count), b = (float)(q / count), gi = gamma[c] * is;
+  const size_t pb = (size_t)plane * HW;
+  const int lo = blockIdx.x * kBnBig, hi = min(HW, lo + kBnBig);
+  for (int i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+    if (i + 4 <= hi) {
+      const f32x4u d = *reinterpret_cast<const f32x4u*>(dy + pb + i), zz = *reinterpret_cast<const f32x4u*>(z + pb + i);
+      f32x4u o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (zz[e] - mu) * is;
+        o[e] = gi * (d[e] - a - xh * b);
+      }
+      *reinterpret_cast<f32x4u*>(dz + pb + i) = o;
+    } else {
+      for (int e = i; e < hi; ++e) {
+        const float xh = (z[pb + e] - mu) * is;
+        dz[pb + e] = gi * (dy[pb + e] - a - xh * b);
+      }
+    }
+  }
+}
+
 // partial pairs (as bn_stats) of sum dy, sum dy * xhat,  xhat = (z - mean)*invstd
 __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ z,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd, int C,
@@ -773,6 +890,38 @@ extern "C" int dasac_bn_bwd_reduce(const float* dy, const float* z, const float*
   DASAC_CHECK_LAUNCH("bn_bwd_reduce");
   hipLaunchKernelGGL(bn_sums_finish, dim3(C), dim3(64), 0, s, partial, N, C, chunks, sums, dbeta, dgamma);
   DASAC_CHECK_LAUNCH("bn_sums_finish");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_train_apply_tiles(const float* z, const float* tile_stats, int n_tiles, int mpad, double count,
+                                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                          int64_t* num_batches_tracked, float momentum, float eps, const float* res, int relu,
+                                          int N, int C, int64_t HW, float* y, float* mean, float* invstd, dasac_stream_t stream) {
+  DASAC_REQUIRE(z && tile_stats && gamma && beta && y && mean && invstd && n_tiles > 0 && mpad >= C && count > 0 && N > 0 && C > 0 &&
+                    HW > 0 && HW < (1ll << 31) && (int64_t)N * C < 65536,
+                "bn_train_apply_tiles: bad arguments");
+  hipLaunchKernelGGL(bn_apply_tiles, dim3((unsigned)((HW + kBnBig - 1) / kBnBig), N * C), dim3(256), 0, as_stream(stream), z, tile_stats,
+                     n_tiles, mpad, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, res, relu, C,
+                     (int)HW, y, mean, invstd);
+  DASAC_CHECK_LAUNCH("bn_apply_tiles");
+  return DASAC_OK;
+}
+
+extern "C" int dasac_bn_bwd_fused(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma,
+                                  double count, int N, int C, int64_t HW, float* dz, float* dgamma, float* dbeta, void* workspace,
+                                  size_t ws_bytes, dasac_stream_t stream) {
+  DASAC_REQUIRE(dy && z && mean && invstd && gamma && dz && workspace && count > 0 && N > 0 && C > 0 && HW > 0 && HW < (1ll << 31) &&
+                    (int64_t)N * C < 65536,
+                "bn_bwd_fused: bad arguments");
+  if (ws_bytes < dasac_bn_stats_workspace(N, C, HW)) return fail(DASAC_EWORKSPACE, "bn_bwd_fused: workspace too small");
+  hipStream_t s = as_stream(stream);
+  const int chunks = (int)((HW + kBnChunk - 1) / kBnChunk);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(bn_bwd_reduce, dim3((unsigned)chunks, N * C), dim3(256), 0, s, dy, z, mean, invstd, C, (int)HW, partial);
+  DASAC_CHECK_LAUNCH("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_apply_partials, dim3((unsigned)((HW + kBnBig - 1) / kBnBig), N * C), dim3(256), 0, s, dy, z, mean, invstd,
+                     gamma, partial, N, chunks, count, C, (int)HW, dz, dgamma, dbeta);
+  DASAC_CHECK_LAUNCH("bn_bwd_apply_partials");
   return DASAC_OK;
 }
 

@@ -61,6 +61,8 @@ PROTOTYPES = {
     "dasac_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p, _p, _p, _sz, _p]),
     "dasac_bn_train_finalize_tiles": (_i, [_p, _i, _i, C.c_double, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
     "dasac_bn_tile_stats_reduce": (_i, [_p, _i, _i, _i, _p, _p]),
+    "dasac_bn_train_apply_tiles": (_i, [_p, _p, _i, _i, C.c_double, _p, _p, _p, _p, _p, _f, _f, _p, _i, _i, _i, _l, _p, _p, _p, _p]),
+    "dasac_bn_bwd_fused": (_i, [_p, _p, _p, _p, _p, C.c_double, _i, _i, _l, _p, _p, _p, _p, _sz, _p]),
     "dasac_conv_gemm_stats_ok": (_i, [_i, _i]),
     "dasac_conv_gemm_stats_tiles": (_i, [_i, _i, _i]),
     "dasac_conv_gemm_stats": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _i, _i, _i, _i, _p, _sz, _p, _p]),

@@ -786,11 +786,17 @@ def bn_train_forward(z, bn, res=None, relu=False, update_running=True, tile_stat
     tail = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr() if upd else None, bn.running_var.data_ptr() if upd else None,
             bn.num_batches_tracked.data_ptr() if upd else None, float(mom), float(bn.eps), Cn, scale.data_ptr(), shift.data_ptr(),
             mean.data_ptr(), invstd.data_ptr(), L.stream_ptr())
-    if tile_stats is not None and _world() == 1:
-        # one rank: the finalize kernel adds the tiles itself -- ONE small launch per BN layer, no pass over z
+    if tile_stats is not None and _world() == 1 and N * Cn < 65536:
+        # one rank: ONE launch per BN layer -- every block adds its channel's tile statistics itself, then normalises its chunk
         count, count_dev = float(N * HW), None
-        L.check(lib.dasac_bn_train_finalize_tiles(tile_stats.data_ptr(), tile_stats.shape[0], tile_stats.shape[2], count, *tail),
-                "dasac_bn_train_finalize_tiles")
+        y = torch.empty_like(z)
+        L.check(lib.dasac_bn_train_apply_tiles(z.data_ptr(), tile_stats.data_ptr(), tile_stats.shape[0], tile_stats.shape[2], count,
+                                               tail[0], tail[1], tail[2], tail[3], tail[4], tail[5], tail[6], L.ptr(res), int(relu),
+                                               N, Cn, HW, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), L.stream_ptr()),
+                "dasac_bn_train_apply_tiles")
+        if upd:
+            bump_versions([bn.running_mean, bn.running_var, bn.num_batches_tracked])
+        return y, (mean, invstd, count, count_dev)
     else:
         if tile_stats is not None:
             sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
@@ -818,9 +824,16 @@ def bn_train_backward(dy, z, stats, gamma, want_params=True, outs=(None, None)):
     dy = _c(dy)
     dg = _dest(outs[0], gamma) if want_params else None
     db = _dest(outs[1], gamma) if want_params else None
-    # the reduction's finish kernel also writes d gamma / d beta -- this rank's LOCAL sums (DDP averages them afterwards)
-    sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
     ws = L.workspace(lib.dasac_bn_stats_workspace(N, Cn, HW), z.device)
+    if _world() == 1 and count_dev is None and N * Cn < 65536:
+        # one rank: reduction stage 1 + ONE kernel that adds the partials per block, forms dz and writes d gamma / d beta
+        dz = torch.empty_like(z)
+        L.check(lib.dasac_bn_bwd_fused(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), float(count),
+                                       N, Cn, HW, dz.data_ptr(), L.ptr(dg), L.ptr(db), ws.data_ptr(), ws.numel(), L.stream_ptr()),
+                "dasac_bn_bwd_fused")
+        return dz, dg, db
+    # several ranks: the finish kernel also writes d gamma / d beta -- this rank's LOCAL sums (DDP averages them afterwards)
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=z.device)
     L.check(lib.dasac_bn_bwd_reduce(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), N, Cn, HW, sums.data_ptr(),
                                     L.ptr(dg), L.ptr(db), ws.data_ptr(), ws.numel(), L.stream_ptr()), "dasac_bn_bwd_reduce")
     if _world() > 1:

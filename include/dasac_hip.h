@@ -314,6 +314,17 @@ int dasac_bn_train_finalize_tiles(const float* tile_stats, int n_tiles, int mpad
                                   int64_t* num_batches_tracked, float momentum, float eps, int C,
                                   float* scale, float* shift, float* mean, float* invstd, dasac_stream_t stream);
 int dasac_bn_tile_stats_reduce(const float* tile_stats, int n_tiles, int C, int mpad, double* sums, dasac_stream_t stream);
+/* One rank, nothing to all-reduce between statistics and use: finalize + normalise in ONE launch per BN layer
+ * (dasac_bn_train_apply_tiles = dasac_bn_train_finalize_tiles + dasac_bn_apply; every block re-adds its channel's tile statistics
+ * in the same fixed order), and the whole BN backward in two (dasac_bn_bwd_fused = the reduction's first stage + a dz kernel whose
+ * blocks add the (plane, chunk) partials themselves and also write d gamma / d beta; workspace of dasac_bn_stats_workspace bytes). */
+int dasac_bn_train_apply_tiles(const float* z, const float* tile_stats, int n_tiles, int mpad, double count,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float momentum, float eps, const float* res, int relu,
+                               int N, int C, int64_t HW, float* y, float* mean, float* invstd, dasac_stream_t stream);
+int dasac_bn_bwd_fused(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma,
+                       double count, int N, int C, int64_t HW, float* dz, float* dgamma, float* dbeta,
+                       void* workspace, size_t ws_bytes, dasac_stream_t stream);
 int dasac_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu,
                    int N, int C, int64_t HW, float* y, dasac_stream_t stream);
 int dasac_bn_bwd_reduce(const float* dy, const float* z, const float* mean, const float* invstd,

@@ -326,7 +326,20 @@ def test_gemm_epilogue_channel_statistics(case):
     assert float((s - od.sum((0, 2, 3))).abs().max()) <= 1e-6 * float(od.abs().sum((0, 2, 3)).max())
     assert float(((q - (od * od).sum((0, 2, 3))) / (od * od).sum((0, 2, 3))).abs().max()) <= 1e-6
     bn_a, bn_b = nn.BatchNorm2d(cout).cuda(), nn.BatchNorm2d(cout).cuda()
-    ya, (mean_a, inv_a, _, _) = ops.bn_train_forward(out, bn_a, None, True, tile_stats=ts)
-    yb, (mean_b, inv_b, _, _) = ops.bn_train_forward(out, bn_b, None, True)
+    res = torch.randn(out.shape, generator=g).cuda()
+    ya, (mean_a, inv_a, _, _) = ops.bn_train_forward(out, bn_a, res, True, tile_stats=ts)     # finalize + apply in one launch
+    yb, (mean_b, inv_b, _, _) = ops.bn_train_forward(out, bn_b, res, True)                    # stats pass, finalize, apply
     assert rel_err(mean_a, mean_b) < 1e-6 and rel_err(inv_a, inv_b) < 1e-6 and rel_err(ya, yb) < 1e-5
-    assert rel_err(bn_a.running_var, bn_b.running_var) < 1e-6 and int(bn_a.num_batches_tracked) == 1
+    assert rel_err(bn_a.running_var, bn_b.running_var) < 1e-6 and rel_err(bn_a.running_mean, bn_b.running_mean) < 1e-6
+    assert int(bn_a.num_batches_tracked) == 1 and int(bn_b.num_batches_tracked) == 1
+    ref = torch.relu(torch.nn.functional.batch_norm(out.cpu(), None, None, None, None, True, 0.1, 1e-5) + res.cpu())
+    assert rel_err(ya, ref) < 1e-5
+    # and the backward pair: stage-1 partials + one dz kernel that also writes d gamma / d beta, against autograd on the CPU
+    zc = out.cpu().clone().requires_grad_(True)
+    gam = (torch.rand(cout, generator=g) + 0.5)
+    dyc = torch.randn(out.shape, generator=g)
+    gamr = gam.clone().requires_grad_(True)
+    yc = torch.nn.functional.batch_norm(zc, None, None, gamr, torch.zeros(cout, requires_grad=True), True, 0.1, 1e-5)
+    yc.backward(dyc)
+    dz, dg, db = ops.bn_train_backward(dyc.cuda(), out, (mean_a, inv_a, float(N * OH * OW), None), gam.cuda())
+    assert rel_err(dz, zc.grad) < 1e-4 and rel_err(dg, gamr.grad) < 1e-4 and rel_err(db, dyc.sum((0, 2, 3))) < 1e-5
