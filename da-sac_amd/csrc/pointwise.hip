@@ -525,10 +525,23 @@ __global__ __launch_bounds__(256) void bn_stats(const float* __restrict__ z, int
   const int plane = blockIdx.y;
   const float* p = z + (size_t)plane * HW;
   double s = 0, q = 0;
-  for (int i = blockIdx.x * kBnChunk + threadIdx.x; i < min(HW, (int)(blockIdx.x + 1) * kBnChunk); i += 256) {
-    const double v = p[i];
-    s += v;
-    q += v * v;
+  const int hi = min(HW, (int)(blockIdx.x + 1) * kBnChunk);
+  for (int i = blockIdx.x * kBnChunk + threadIdx.x * 4; i < hi; i += 256 * 4) {      // 16-byte loads (4-byte aligned planes)
+    if (i + 4 <= hi) {
+      const f32x4u v4 = *reinterpret_cast<const f32x4u*>(p + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double v = v4[e];
+        s += v;
+        q += v * v;
+      }
+    } else {
+      for (int e = i; e < hi; ++e) {
+        const double v = p[e];
+        s += v;
+        q += v * v;
+      }
+    }
   }
   __shared__ double rs[4], rq[4];
   s = wave_sum(s);
@@ -765,10 +778,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const float* __restrict__ d
   const float* pz = z + (size_t)plane * HW;
   const float m = mean[c], is = invstd[c];
   double s = 0, q = 0;
-  for (int i = blockIdx.x * kBnChunk + threadIdx.x; i < min(HW, (int)(blockIdx.x + 1) * kBnChunk); i += 256) {
-    const float d = pd[i];
-    s += d;
-    q += (double)d * (double)((pz[i] - m) * is);
+  const int hi = min(HW, (int)(blockIdx.x + 1) * kBnChunk);
+  for (int i = blockIdx.x * kBnChunk + threadIdx.x * 4; i < hi; i += 256 * 4) {      // 16-byte loads (4-byte aligned planes)
+    if (i + 4 <= hi) {
+      const f32x4u d4 = *reinterpret_cast<const f32x4u*>(pd + i), z4 = *reinterpret_cast<const f32x4u*>(pz + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s += d4[e];
+        q += (double)d4[e] * (double)((z4[e] - m) * is);
+      }
+    } else {
+      for (int e = i; e < hi; ++e) {
+        const float d = pd[e];
+        s += d;
+        q += (double)d * (double)((pz[e] - m) * is);
+      }
+    }
   }
   __shared__ double rs[4], rq[4];
   s = wave_sum(s);
