@@ -30,7 +30,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBK = 16;            // K-step of the forward/dgrad kernel
 constexpr int kThreads = 256;      // 4 waves
 constexpr int kInvalid = 1 << 20;  // dh of a padded table row: never in bounds
-constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
+#ifndef DASAC_SK_PER_CU
+#define DASAC_SK_PER_CU 3                                // experiment builds: -DDASAC_SK_PER_CU=4 (128 registers, spills: see DESIGN 5a)
+#endif
+constexpr int kSkWorkersPerCu = DASAC_SK_PER_CU;         // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
 constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8: the grid of every stream-K launch
 
 #ifdef DASAC_TRACE_TILES
@@ -191,7 +194,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 //       2 = the epilogue masks with a recorded bit pattern (Epilogue::mbits).  Separate instantiations, so that the plain
 //       kernels carry none of the extra scalar state.
 template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3, int BITS = 0>
-__global__ __launch_bounds__(kThreads, STREAMK ? 3 : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
+__global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
                                                       float* __restrict__ partial, int* __restrict__ flags) {

@@ -625,39 +625,19 @@ __device__ __forceinline__ float take(const float* __restrict__ pl, const Sample
   return pl[s.o00] * s.w00 + pl[s.o01] * s.w01 + pl[s.o10] * s.w10 + pl[s.o11] * s.w11;
 }
 
-// Warp kernels walk the output in 64 x 4 pixel TILES (a wave = 64 consecutive pixels of one row, the block's four waves = four
-// adjacent rows): bilinear taps of vertically adjacent outputs share a source row, and with a block spanning four rows that row
-// is fetched once per block instead of once per (distant) block of the linear pixel order -- the counters showed `warp_back`
-// moving 2.4x and `warp_pool` 1.4x their algorithmic bytes (profiles/r4_head_kernel_pmc.md), i.e. bound by over-fetch.
-// Per-pixel arithmetic is untouched: outputs are bit-identical.
-struct TileWalk {
-  int tiles_x, n_tiles;
-};
-__device__ __forceinline__ TileWalk tile_walk(int H, int W) {
-  TileWalk t;
-  t.tiles_x = (W + 63) >> 6;
-  t.n_tiles = t.tiles_x * ((H + 3) >> 2);
-  return t;
-}
-__device__ __forceinline__ bool tile_pixel(const TileWalk& t, int tile, int H, int W, int& oy, int& ox) {
-  const int ty = tile / t.tiles_x, tx = tile - ty * t.tiles_x;
-  oy = ty * 4 + (threadIdx.x >> 6);
-  ox = tx * 64 + (threadIdx.x & 63);
-  return oy < H && ox < W;
-}
-
+// (Round 4, measured and rejected: walking the output in 64 x 4 pixel tiles -- a wave per row segment, four adjacent rows per block,
+// so that vertically adjacent outputs share their source row inside a block -- to cut the over-fetch the counters show for these
+// kernels (`warp_back` moves 2.4x, `warp_pool` 1.4x its algorithmic bytes: profiles/r4_head_kernel_pmc.md).  `warp_pool` went
+// 294 -> 755 us, `warp_back` 220 -> 245 us: the linear pixel order keeps every wave's 19 x T class-plane streams sequential in
+// DRAM, the tile order breaks each of them into 256-byte pieces three rows apart.  The linear order stays.)
 // generic warp of a [B,C,H,W] tensor (frames_aligned diagnostic)
 __global__ __launch_bounds__(kHB) void warp_affine(const float* __restrict__ x, const float* __restrict__ theta, int C,
                                                    int H, int W, float* __restrict__ out, int blocks_per_image) {
   const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
   const int HW = H * W;
   const float* th = theta + b * 6;
-  const TileWalk tw = tile_walk(H, W);
-  for (int tile = chunk; tile < tw.n_tiles; tile += blocks_per_image) {
-    int oy, ox;
-    if (!tile_pixel(tw, tile, H, W, oy, ox)) continue;
-    const int p = oy * W + ox;
-    const Sample s = make_sample(th, oy, ox, H, W);
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const Sample s = make_sample(th, p / W, p % W, H, W);
     for (int c = 0; c < C; ++c) {
       const size_t pb = ((size_t)b * C + c) * HW;
       out[pb + p] = take(x + pb, s);
@@ -763,11 +743,8 @@ __global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ p
                                                      float* __restrict__ mask, int blocks_per_group) {
   const int n = blockIdx.x / blocks_per_group, chunk = blockIdx.x % blocks_per_group;
   const int HW = H * W;
-  const TileWalk tw = tile_walk(H, W);
-  for (int tile = chunk; tile < tw.n_tiles; tile += blocks_per_group) {
-    int oy, ox;
-    if (!tile_pixel(tw, tile, H, W, oy, ox)) continue;
-    const int p = oy * W + ox;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_group * kHB) {
+    const int oy = p / W, ox = p - oy * W;
     Sample s[TT];
     float cov[TT];
 #pragma unroll
@@ -810,12 +787,8 @@ __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ poole
   const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
   const int n = b / group_div;
   const int HW = H * W;
-  const TileWalk tw = tile_walk(H, W);
-  for (int tile = chunk; tile < tw.n_tiles; tile += blocks_per_image) {
-    int oy, ox;
-    if (!tile_pixel(tw, tile, H, W, oy, ox)) continue;
-    const int p = oy * W + ox;
-    const Sample s = make_sample(theta_inv + b * 6, oy, ox, H, W);
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const Sample s = make_sample(theta_inv + b * 6, p / W, p % W, H, W);
     const float mv = take(mask + (size_t)n * HW, s);
     for (int c = 0; c < C; ++c)
       refined[((size_t)b * C + c) * HW + p] = take(pooled + ((size_t)n * C + c) * HW, s) * mv;
