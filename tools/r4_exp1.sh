@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the DASAC_EXP_BM64_KSTEPS switch this script drives existed only for the measurement (profiles/r4_bm64_occupancy5_experiment.txt);
+# it was removed again, so the bm64_* runs now equal "base".
 # round-4 measurement batch 1 (run through gpurun from the repo root)
 O=gpurun_out/r4c; mkdir -p $O
 python -m pytest tests/test_gpu_conv.py tests/test_gpu_bn_train.py tests/test_gpu_head.py tests/test_gpu_zz_determinism.py -m gpu -x -q --durations=8 > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log

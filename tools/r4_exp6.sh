@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: needs a second library built with -DDASAC_SK_PER_CU=4 at da-sac_amd/dasac_hip/libdasac_hip_sk4.so (see profiles/r4_streamk_4_workers_experiment.txt).
 # stream-K at FOUR workers per CU (128 registers, spills) against the shipped three (168 registers): whole-step effect
 O=gpurun_out/r4h; mkdir -p $O
 R=$PWD
