@@ -12,6 +12,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 
 namespace dasac {
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
   }
 }
 
+// (Round 4, measured and rejected: a two-pixels-per-thread variant of the probs path -- 152 instead of 225 VGPRs, three instead of two
+// waves per SIMD, 8-byte stores -- runs 238 us against this kernel's 214 at 8 x 19 x 769^2, 297 us when forced to four waves per SIMD
+// with 92 bytes of scratch: sharing the low-resolution taps among four pixels and the dwordx4 stores outweigh the occupancy.)
 // class sums: Q32 fixed point -> double, in place (the caller's buffer holds 8-byte slots either way)
 __global__ void q32_to_double(unsigned long long* __restrict__ q, int C) {
   const int c = threadIdx.x;
@@ -458,12 +462,22 @@ __host__ __device__ __forceinline__ int ce_lds_index(int x) { return x + (x >> 3
 // two serial phases rarely overlapped) -- six 128-thread blocks per CU, phases of different blocks overlap.  The pixels between
 // two segments' column ranges are evaluated by both (softmax is per pixel: same bits); every column is summed by ONE block over
 // ascending x exactly as before, so the result stays bit-identical to dasac_ce_loss(dlogits) + dasac_upsample_bwd.
+// cs[p] = sum_i conf_i[p] in image order (0 + c_0 + c_1 + ...: the order every row block used to repeat for itself, B times over)
+__global__ __launch_bounds__(256) void conf_pixel_sums(const float* __restrict__ conf, int B, int HW, float* __restrict__ cs) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    float a = 0.f;
+    for (int bb = 0; bb < B; ++bb) a += conf[(size_t)bb * HW + p];
+    cs[p] = a;
+  }
+}
+
 constexpr int kCB = 128;
 template <int CT>
 __global__ __launch_bounds__(kCB) void ce_bwd_rows(const float* __restrict__ xup, const int64_t* __restrict__ y,
                                                   const float* __restrict__ cw, const float* __restrict__ conf, int B, int Crt,
                                                   int H, int W, int w, float sw, int mode, const float* __restrict__ gscale,
-                                                  float* __restrict__ tmp, int seg_cols, int n_seg, int pitch) {
+                                                  float* __restrict__ tmp, int seg_cols, int n_seg, int pitch,
+                                                  const float* __restrict__ cs_pix) {
   extern __shared__ float s_d[];                      // [C][pitch]
   const int C = CT < kMaxC ? CT : Crt;
   const int seg = blockIdx.x % n_seg, rowid = blockIdx.x / n_seg;
@@ -501,7 +515,11 @@ __global__ __launch_bounds__(kCB) void ce_bwd_rows(const float* __restrict__ xup
     if (mode == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) cs[e] = 0.f;
-      if (nx == 4) {
+      if (cs_pix) {                                       // sum_i conf_i per pixel, added up ONCE per launch (conf_pixel_sums)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nx) cs[e] = cs_pix[p + e];
+      } else if (nx == 4) {
 #pragma unroll 8
         for (int bb = 0; bb < B; ++bb) {
           const f32x4u cv = *reinterpret_cast<const f32x4u*>(conf + (size_t)bb * HW + p);
@@ -920,7 +938,13 @@ extern "C" int dasac_ce_loss(const float* logits, const int64_t* labels, const f
   return DASAC_OK;
 }
 
-extern "C" size_t dasac_ce_loss_bwd_low_workspace(int B, int C, int H, int w) { return (size_t)B * C * H * w * sizeof(float); }
+// tmp [B*C][H][w] floats, then (rounded up to 256 bytes) room for the per-pixel confidence sums of mode 1: H * kCeMaxW floats would
+// over-allocate, so the sums live in the tail only when H * W is known to fit -- the launcher checks ws_bytes and falls back
+static size_t ce_bwd_tmp_bytes(int B, int C, int H, int w) { return align_up((size_t)B * C * H * w * sizeof(float), 256); }
+extern "C" size_t dasac_ce_loss_bwd_low_workspace(int B, int C, int H, int w) {
+  // the confidence sums need H*W floats; W is not an argument here: w * 16 covers every up-factor to 16 (the backbone's is 8)
+  return ce_bwd_tmp_bytes(B, C, H, w) + (size_t)H * w * 16 * sizeof(float);
+}
 
 extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labels, const float* class_weight, const float* conf,
                                      int B, int C, int H, int W, int h, int w, int mode, const float* gscale, float* grad_low,
@@ -929,7 +953,7 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
   DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && H > 0 && W > 0 && h > 0 && w > 0 && (int64_t)H * W < (1ll << 31) &&
                     (mode == 0 || (mode == 1 && conf)),
                 "ce_loss_bwd_low: bad arguments");
-  if (ws_bytes < dasac_ce_loss_bwd_low_workspace(B, C, H, w)) return fail(DASAC_EWORKSPACE, "ce_loss_bwd_low: workspace too small");
+  if (ws_bytes < ce_bwd_tmp_bytes(B, C, H, w)) return fail(DASAC_EWORKSPACE, "ce_loss_bwd_low: workspace too small");
   // segments of low-resolution columns per block: the x range of a segment (+ the taps' reach on both sides) bounds the LDS
   // row; ~300 pixels (about 24 KB for 19 classes) lets six blocks share a CU
   const float sw = ac_scale(w, W);
@@ -962,12 +986,21 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
     }
   }
   DASAC_REQUIRE((int64_t)B * H * n_seg < (1ll << 31), "ce_loss_bwd_low: grid too large");
+  // mode 1: every image's rows need sum_i conf_i of their pixels -- B x B plane reads if each block adds them up itself; one pass
+  // into the workspace tail instead (when the caller's workspace has the room: H * W floats behind tmp)
+  const float* cs_pix = nullptr;
+  if (mode == 1 && B > 1 && ws_bytes >= ce_bwd_tmp_bytes(B, C, H, w) + (size_t)H * W * sizeof(float)) {
+    float* cs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ce_bwd_tmp_bytes(B, C, H, w));
+    hipLaunchKernelGGL(conf_pixel_sums, dim3(stream_grid((int64_t)H * W, 256)), dim3(256), 0, s, conf, B, H * W, cs);
+    DASAC_CHECK_LAUNCH("conf_pixel_sums");
+    cs_pix = cs;
+  }
   if (C == 19)
     hipLaunchKernelGGL(ce_bwd_rows<19>, dim3(B * H * n_seg), dim3(kCB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
-                       sw, mode, gscale, tmp, seg_cols, n_seg, pitch);
+                       sw, mode, gscale, tmp, seg_cols, n_seg, pitch, cs_pix);
   else
     hipLaunchKernelGGL(ce_bwd_rows<kMaxC>, dim3(B * H * n_seg), dim3(kCB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
-                       sw, mode, gscale, tmp, seg_cols, n_seg, pitch);
+                       sw, mode, gscale, tmp, seg_cols, n_seg, pitch, cs_pix);
   DASAC_CHECK_LAUNCH("ce_bwd_rows");
   const int64_t t2 = (int64_t)B * C * h * w;
   hipLaunchKernelGGL(upsample_bwd_y, dim3(stream_grid(t2, kHB)), dim3(kHB), 0, s, tmp, H, h, w, ac_scale(h, H), nullptr, grad_low, t2);

@@ -216,7 +216,10 @@ int dasac_ce_loss(const float* logits, const int64_t* labels, const float* class
                   dasac_stream_t stream);
 /* Gradient of dasac_ce_loss w.r.t. the LOW-resolution logits the upsampled ones came from (deeplabv2.py:217 then
  * :223-224 / sac.py:119-149): grad_low [B,C,h,w] = gscale[0] * U^T (d loss / d logits_up) without materialising the
- * full-resolution gradient (same arithmetic and summation order as dasac_ce_loss(dlogits) + dasac_upsample_bwd). */
+ * full-resolution gradient (same arithmetic and summation order as dasac_ce_loss(dlogits) + dasac_upsample_bwd).
+ * The workspace holds the row buffer [B*C][H][w] and, behind it, H*W floats for the per-pixel confidence sums of mode 1
+ * (added up once per launch instead of once per image; the size function reserves H*w*16 floats = any up-factor to 16; a
+ * workspace with only the row buffer still works, every block then adds the B confidences itself). */
 size_t dasac_ce_loss_bwd_low_workspace(int B, int C, int H, int w);
 int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labels, const float* class_weight, const float* conf,
                           int B, int C, int H, int W, int h, int w, int mode, const float* gscale, float* grad_low,

@@ -265,6 +265,9 @@ def test_upsample_softmax_four_pixels_per_thread_edges(shape):
     assert rel_err(up, ref_up) < TOL
     assert rel_err(sums, ref_p.sum((0, 2, 3))) < 1e-5
     assert rel_err(probs, ref_p * (~ign)[:, None]) < TOL
+    # the teacher's path (no upsampled logits wanted): same kernel, `up` not written -- identical probabilities and sums
+    _, probs2, sums2 = ops.upsample_softmax(x.cuda(), (Hh, W), ign.cuda(), want_up=False, want_probs=True, want_sums=True)
+    assert torch.equal(probs2, probs) and torch.equal(sums2, sums)
 
 
 def test_label_pad_mask_class_sums_and_dropout_planes():
