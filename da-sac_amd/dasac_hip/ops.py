@@ -631,7 +631,8 @@ def maxpool_bwd(dy, y, arg, in_hw, k, s, p, relu_mask):
     B, Cn, OH, OW = dy.shape
     H, W = in_hw
     dx = _f32((B, Cn, H, W), dy)
-    with PROFILE.span("maxpool_bwd", 0.0, None, dx.numel() * 4.0 + dy.numel() * 9.0):
+    # algorithmic bytes: dx written, dy + the argmax byte read; the pooled tensor only for windows beyond 11x11 (bit 7 of the byte)
+    with PROFILE.span("maxpool_bwd", 0.0, None, dx.numel() * 4.0 + dy.numel() * (9.0 if (relu_mask and k > 11) else 5.0)):
         L.check(lib.dasac_maxpool_bwd(dy.data_ptr(), y.data_ptr(), arg.data_ptr(), B * Cn, H, W, OH, OW, k, s, p, int(relu_mask),
                                       dx.data_ptr(), L.stream_ptr()), "dasac_maxpool_bwd")
     return dx

@@ -45,7 +45,7 @@ x = torch.randn(B, 64, 385, 385, device="cuda")
 yp, arg = ops.maxpool_fwd(x, 3, 2, 1, True)
 dy = torch.randn_like(yp)
 rows.append(("maxpool_fwd 3x3/2 ceil", x.numel() * 4 + yp.numel() * 5, timeit(lambda: ops.maxpool_fwd(x, 3, 2, 1, True))))
-rows.append(("maxpool_bwd (+ReLU mask)", x.numel() * 4 + yp.numel() * 9, timeit(lambda: ops.maxpool_bwd(dy, yp, arg, (385, 385), 3, 2, 1, True))))
+rows.append(("maxpool_bwd (+ReLU mask)", x.numel() * 4 + yp.numel() * 5, timeit(lambda: ops.maxpool_bwd(dy, yp, arg, (385, 385), 3, 2, 1, True))))
 a = torch.randn(B, 1024, 97, 97, device="cuda")
 rows.append(("relu_mask", 3 * a.numel() * 4, timeit(lambda: ops.relu_mask(a, a))))
 print("{:44s} {:>9s} {:>9s} {:>8s} {:>7s}".format("kernel", "MB", "us", "TB/s", "of 8"))
