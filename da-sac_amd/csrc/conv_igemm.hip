@@ -1564,7 +1564,14 @@ static int wgrad_bn(int Cx) { return (Cx % 128 != 0 && Cx % 64 == 0) ? 64 : 128;
 static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM, int BNk = 128) {
   const int tiles = (Mpad / BM) * (Kpad / BNk);
   const int slots = kNumCu * 3;
-  int max_splits = (Npix + 1023) / 1024;                    // at least 1024 pixels per split
+  // At least 256 pixels (8 K-steps) per split.  Rounds 1-3 asked for 1024: at batch 2 (cfg-2: 18 818 pixels) that capped the 16-tile
+  // 1x1 layers at 19 splits = 304 blocks for 768 slots; measured in round 4 (profiles/r4_wgrad_split_granularity.txt, cfg-2):
+  // 1024 -> 512 -> 256 pixels: weight gradients 18.7 -> 16.3 -> 15.4 ms/step (90 -> 103 -> 109 TFLOP/s).  Large batches are
+  // unaffected (the cap of 64 splits binds first).
+#ifndef DASAC_WG_MINPIX
+#define DASAC_WG_MINPIX 256
+#endif
+  int max_splits = (Npix + DASAC_WG_MINPIX - 1) / DASAC_WG_MINPIX;
   // few tiles x many pixels (layer1 / stem: 2 tiles, 298k..1.2M pixels): more splits, or 128 blocks would face 768 slots
   const int cap = (tiles < 12 && Npix >= 200000) ? (slots + tiles - 1) / tiles : 64;   // measured: no gain at 97x97 resolution
   if (max_splits > cap) max_splits = cap;
