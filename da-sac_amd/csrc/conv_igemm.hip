@@ -1408,8 +1408,11 @@ extern "C" int dasac_conv_gemm_plan(int Nb, int OH, int OW, int M, int K) {
   if (!mode || pick_bm(Mpad) != 128) return 0;
   const int m_tiles = (M + 127) / 128, n_tiles = (Nb * OH * OW + 127) / 128, k_steps = (K + kBK - 1) / kBK;
   const int tiles = m_tiles * n_tiles;
-  if (!want_streamk(tiles, k_steps)) return 0;
   const int slots = kNumCu * 4;                                  // resident blocks of the tile-per-block kernel
+  // (Round 4, measured and rejected: extending this split to the short-K layers -- 16 <= K-steps < 64, many whole rounds plus a last
+  // one filled below half -- moves 59 more launches per cfg-3 step to stream-K: one block per tile 248.5 -> 246.9 ms, stream-K
+  // 28.9 -> 32.6 ms.  A remainder launch costs its ~25 us of ramp and hand-off whatever it saves of a thin last round.)
+  if (!want_streamk(tiles, k_steps)) return 0;
   const int lead = (tiles / slots) * slots / m_tiles;            // pixel tiles of the leading whole rounds
   if (lead == 0 || lead >= n_tiles) return 0;
   return lead * 128;
