@@ -21,6 +21,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace dasac {
 
@@ -115,13 +116,16 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
   return f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
 
-// v_writelane_b32 with a compile-time lane (this clang has no writelane builtin; the lane select must be an inline constant or
-// M0, and M0 is reserved).  put_mask_rows: the two 32-bit halves of a wave ballot over accumulator register `rg` are the mask
-// words of rows (rg&3) + 8*(rg>>2) (lanes 0-31) and 4 below (lanes 32-63) of a 32x32 MFMA tile: lane r of `acc` collects row r.
+// v_writelane_b32 (this clang exposes no __builtin_amdgcn_writelane; the LLVM intrinsic is reachable through its asm label, the way
+// the HIP headers reach llvm.amdgcn.s.barrier).  Rounds 3-4 emitted the instruction from inline asm, which hides it from the
+// hazard recogniser: gfx940+ needs two wait states between a VALU that writes an SGPR (the ballot's v_cmp) and a VALU that reads it,
+// and only instruction-scheduling luck had put them there.  put_mask_rows: the two 32-bit halves of a wave ballot over accumulator
+// register `rg` are the mask words of rows (rg&3) + 8*(rg>>2) (lanes 0-31) and 4 below (lanes 32-63) of a 32x32 MFMA tile: lane r
+// of `acc` collects row r.
+extern "C" __device__ int dasac_llvm_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 template <int LANE>
 __device__ __forceinline__ int writelane_c(int val, int old) {
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(LANE));
-  return old;
+  return dasac_llvm_writelane(val, LANE, old);
 }
 __device__ __forceinline__ int put_mask_rows(int rg, unsigned long long ballot, int acc) {
   const int lo = (int)(unsigned)ballot, hi = (int)(unsigned)(ballot >> 32);
@@ -212,6 +216,13 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
 
   __shared__ f32x4 sA[2][KQ * BM];
   __shared__ f32x4 sB[2][KQ * BN];
+  // Epilogue operands that are per ROW (shift) or per row and 32-pixel group (mask words) wait in LDS from the tile's prologue
+  // on: the epilogue then contains no vector-memory load except the residual's.  That matters because gfx9's vmcnt retires
+  // loads AND stores in issue order -- a wait for any load issued after a store is also a wait for that store's
+  // acknowledgement; rounds 1-4 interleaved 8 batches of (loads, 8 stores) and paid 8 store round trips per tile
+  // (28-36 us of a 91 us workgroup life on the K = 256 layers, profiles/r3_tile_timeline.txt).
+  __shared__ __attribute__((aligned(16))) float s_shift[BM];
+  __shared__ __attribute__((aligned(16))) unsigned s_mbits[BITS == 2 ? (BN / 32) * BM : 4];   // [32-pixel group][row]
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform on purpose: scalar buffer offsets
@@ -260,7 +271,10 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     it_end = it + KT;
   }
 
-  while (it < it_end) {
+  // (a do-while whose back edge exists only in the persistent variant: the tile-per-block kernel runs the body once -- it returned
+  // above if it has no tile --, and the compiler must SEE that, or every K-loop invariant stays live across the epilogue
+  // and its register pressure pushes them into spill slots that are then re-read inside the K loop)
+  do {
     const int tile = it / KT;
     const int ks = it - tile * KT;
     const int ke = min(KT, ks + (it_end - it));
@@ -352,8 +366,31 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     DASAC_STAMP(0);
+    // the tile's per-row epilogue operands (consumed only by the worker that runs the epilogue: ks == 0)
+    float pro_shift = 0.f;
+    unsigned pro_bits[BITS == 2 ? (BN / 32) * BM / kThreads : 1];
+    if (!STREAMK || ks == 0) {
+      if (t < BM) pro_shift = buf_f32(rsh, (unsigned)(m0 + t) * 4u, 0);      // rows past M (and a null shift: 0 records) read 0
+      if constexpr (BITS == 2) {
+        static_assert(BITS != 2 || ((BN / 32) * BM) % kThreads == 0, "mask words per tile");
+#pragma unroll
+        for (int u = 0; u < (BN / 32) * BM / kThreads; ++u) {
+          const int idx = t + u * kThreads, c = idx / BM, row = idx - c * BM;
+          const int wcol = (n0 >> 5) + c;
+          pro_bits[u] = __builtin_amdgcn_raw_buffer_load_b32(
+              rmsk, (m0 + row < g.M && wcol < ep.w32) ? (unsigned)((m0 + row) * ep.w32 + wcol) * 4u : kPoison, 0, 0);
+        }
+      }
+    }
     DASAC_LOAD_TILE(ks);
     DASAC_STORE_TILE(ks & 1);
+    if (!STREAMK || ks == 0) {
+      if (t < BM) s_shift[t] = pro_shift;
+      if constexpr (BITS == 2) {
+#pragma unroll
+        for (int u = 0; u < (BN / 32) * BM / kThreads; ++u) s_mbits[t + u * kThreads] = pro_bits[u];
+      }
+    }
     __syncthreads();
     DASAC_STAMP(1);
     for (int kt = ks; kt < ke; ++kt) {
@@ -490,75 +527,118 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
     const bool deposited = STREAMK && ks > 0;                // this worker only contributed a partial sum
     DASAC_STAMP(2);
+#ifndef DASAC_EXP_NOPRIO
+    // VALU issue on a SIMD is arbitrated by priority, then age, and an MFMA waiting for the matrix pipe holds the slot: next to
+    // three waves in their K loops an epilogue wave gets about one vector-ALU instruction per 64-cycle MFMA (measured in round 5:
+    // 21-26 us from the end of the K loop to the last store ISSUED -- with the stores compiled out just the same -- and 2 us for their
+    // acknowledgements).  At priority 3 the epilogue's few hundred VALU instructions issue back to back and the workgroup returns
+    // its slot ~20 us earlier; the matrix pipe loses the same issue slots either way.
+    __builtin_amdgcn_s_setprio(3);
+#endif
     if (!deposited) {
     if constexpr (BITS != 3) {
+    // Per 32-pixel column group j: ONE batch of loads (the residual and / or an fp32 mask, TM x 16 values; shift and mask words
+    // come from LDS), then the arithmetic and the TM x 16 stores.  A layer without residual issues no vector-memory load here
+    // at all -- 64 stores back to back, the workgroup ends one acknowledgement after the last; with a residual the second
+    // batch's wait covers the first batch's stores: two store round trips per tile instead of eight.
+    // FULL: the tile's BM rows all exist (every tile of a layer whose channel count is a multiple of BM): no row tests.
+    // (the plane size is laundered through an empty asm so that none of the 64 per-row scalar offsets derived from it is
+    // computed -- and kept alive in SGPRs, then spilled into VGPR lanes -- ahead of the K loop)
+    int OutHWe = OutHW;
+    asm volatile("" : "+s"(OutHWe));
+    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      // row of accumulator register rg of row group i: mrow + (rg&3) + 8*(rg>>2), + 4*lh in the lane offset -> a row exists
+      // iff its lane-independent part is below M - 4*lh (one per-lane limit, a compare and a select per access)
+      const int mlim = g.M - 4 * lh;
+#define DASAC_ROW(i, rg) (m0 + wm * WM + (i) * 32 + ((rg) & 3) + 8 * ((rg) >> 2))
+#define DASAC_VOFF(i, rg) (FULL ? vo : (DASAC_ROW(i, rg) < mlim ? vo : kPoison))
+      // one batch: row groups I0 .. I0+NI-1 of column group j
+      auto batch = [&](int j, unsigned vo, auto i0_tag, auto ni_tag) __attribute__((always_inline)) {
+        constexpr int I0 = decltype(i0_tag)::value, NI = decltype(ni_tag)::value;
+        const int wcol = (n0 + wn * WN + j * 32) >> 5;          // this wave's 32-pixel group = one word column of the bit masks
+        float rs[NI][16], mk[NI][16];
+        if (ep.res) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int pix = n0 + wn * WN + j * 32 + li;
-      unsigned vo = kPoison;
-      if (pix < g.Npix) {
-        const int n = pix / OHW, r = pix - n * OHW;
-        const int oh = r / g.OW, ow = r - oh * g.OW;
-        vo = (unsigned)(n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHW) * 4u;
-      }
-      const int wcol = (n0 + wn * WN + j * 32) >> 5;          // this wave's 32-pixel group = one word column of the bit masks
-      const unsigned vmb = (unsigned)(4 * lh * ep.w32 + wcol) * 4u;
+          for (int i = I0; i < I0 + NI; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mrow = m0 + wm * WM + i * 32;             // + (rg&3) + 8*(rg>>2) (+4*lh in the lane offset)
-        if (mrow >= g.M) continue;                           // whole 32-row group beyond M (uniform)
-        int bitrows = 0;                                     // producer: lane r collects the mask word of row mrow + r
-        // 8 rows at a time: one batch of loads (shift, residual, mask), then the arithmetic and the stores;
-        // the compiler barrier keeps the batches from being merged (register pressure -> occupancy).
+            for (int rg = 0; rg < 16; ++rg) rs[i - I0][rg] = buf_f32(rres, DASAC_VOFF(i, rg), DASAC_ROW(i, rg) * OutHWe * 4);
+        }
+        if (BITS != 2 && ep.mask) {          // fp32 mask: the ReLU-backward pattern read from the activation itself
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float sh[8], rs[8], mk[8];
-          unsigned vrow[8];
+          for (int i = I0; i < I0 + NI; ++i)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int rg = half * 8 + u;
-            const int mr = mrow + (rg & 3) + 8 * (rg >> 2);
-            // rows past M: uniform test when M % 8 == 0, per-lane otherwise
-            const bool rowok = ragged ? (mr + 4 * lh < g.M) : (mr < g.M);
-            vrow[u] = rowok ? vo : kPoison;
-            sh[u] = ep.shift ? buf_f32(rsh, rowok ? (unsigned)(4 * lh) * 4u : kPoison, mr * 4) : 0.f;
-            if constexpr (BITS == 2)      // one word per (row, 32-pixel group): the 32 lanes of a half-wave read the same 4 bytes
-              mk[u] = buf_f32(rmsk, rowok ? vmb : kPoison, mr * ep.w32 * 4);
-          }
-          if (ep.res) {
+            for (int rg = 0; rg < 16; ++rg) mk[i - I0][rg] = buf_f32(rmsk, DASAC_VOFF(i, rg), DASAC_ROW(i, rg) * OutHWe * 4);
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int rg = half * 8 + u;
-              rs[u] = buf_f32(rres, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
+        for (int i = I0; i < I0 + NI; ++i) {
+          const int mrow = m0 + wm * WM + i * 32;
+          if (!FULL && mrow >= g.M) continue;                  // whole 32-row group beyond M (uniform)
+          const int lrow = wm * WM + i * 32 + 4 * lh;            // + 8*q + e: the four rows of accumulator registers 4q .. 4q+3
+          int bitrows = 0;                                     // producer: lane r collects the mask word of row mrow + r
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(&s_shift[lrow + 8 * q]);
+            u32x4 mb4 = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (BITS == 2) mb4 = *reinterpret_cast<const u32x4*>(&s_mbits[(wn * (WN / 32) + j) * BM + lrow + 8 * q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int rg = 4 * q + e;
+              float v = acc[i][j][rg] + sh4[e];
+              if (ep.res) v = v + rs[i - I0][rg];
+              if (ep.relu) v = fmaxf(v, 0.f);
+              if (BITS != 2 && ep.mask) v = mk[i - I0][rg] > 0.f ? v : 0.f;
+              if constexpr (BITS == 2) v = ((mb4[e] >> li) & 1u) ? v : 0.f;
+#ifndef DASAC_EXP_NOSTORE
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, DASAC_VOFF(i, rg), DASAC_ROW(i, rg) * OutHWe * 4, 0);
+#else
+              if (v == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, DASAC_VOFF(i, rg), DASAC_ROW(i, rg) * OutHWe * 4, 0);
+#endif
+              if constexpr (BITS == 1)      // lanes 0-31 hold row (rg&3) + 8*(rg>>2), lanes 32-63 the row 4 below it: two words per ballot
+                bitrows = put_mask_rows(rg, __builtin_amdgcn_ballot_w64(v > 0.f), bitrows);
             }
           }
-          if (BITS != 2 && ep.mask) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int rg = half * 8 + u;
-              mk[u] = buf_f32(rmsk, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4);
-            }
+          if constexpr (BITS == 1) {
+            // (a 32-pixel group of the last tile may lie entirely past the last pixel: no word exists for it)
+            if (lane < 32 && mrow + lane < g.M && wcol < ep.w32) ep.obits[(size_t)(mrow + lane) * ep.w32 + wcol] = (unsigned)bitrows;
           }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int rg = half * 8 + u;
-            float v = acc[i][j][rg] + sh[u];
-            if (ep.res) v = v + rs[u];
-            if (ep.relu) v = fmaxf(v, 0.f);
-            if (BITS != 2 && ep.mask) v = mk[u] > 0.f ? v : 0.f;
-            if constexpr (BITS == 2) v = ((__float_as_uint(mk[u]) >> li) & 1u) ? v : 0.f;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, vrow[u], (mrow + (rg & 3) + 8 * (rg >> 2)) * OutHW * 4, 0);
-            if constexpr (BITS == 1)      // lanes 0-31 hold row (rg&3) + 8*(rg>>2), lanes 32-63 the row 4 below it: two words per ballot
-              bitrows = put_mask_rows(rg, __builtin_amdgcn_ballot_w64(v > 0.f), bitrows);
-          }
-          asm volatile("" ::: "memory");
         }
-        if constexpr (BITS == 1) {
-          // (a 32-pixel group of the last tile may lie entirely past the last pixel: no word exists for it)
-          if (lane < 32 && mrow + lane < g.M && wcol < ep.w32) ep.obits[(size_t)(mrow + lane) * ep.w32 + wcol] = (unsigned)bitrows;
+        asm volatile("" ::: "memory");     // the next batch's loads stay behind this batch's stores (registers -> occupancy)
+      };
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int pix = n0 + wn * WN + j * 32 + li;
+        unsigned vo = kPoison;
+        if (pix < g.Npix) {
+          const int n = pix / OHW, r = pix - n * OHW;
+          const int oh = r / g.OW, ow = r - oh * g.OW;
+          vo = (unsigned)(n * g.M * OutHWe + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHWe) * 4u;
+        }
+        using c0 = std::integral_constant<int, 0>;
+        using c1 = std::integral_constant<int, 1>;
+        if (TM == 2 && BITS != 2 && ep.res && ep.mask) {   // residual AND fp32 mask: 2 x 16 loaded values per row group -> one group per batch
+          batch(j, vo, c0{}, c1{});
+          if constexpr (TM == 2) batch(j, vo, c1{}, c1{});
+        } else {
+          batch(j, vo, c0{}, std::integral_constant<int, TM>{});
         }
       }
-    }
+#undef DASAC_ROW
+#undef DASAC_VOFF
+    };
+#ifdef DASAC_EXP_NOEPI
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(acc[i][j]));
+#endif
+      }
+#else
+    if (m0 + BM <= g.M) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+#endif
     } else {
       // ---- BITS == 3: raw convolution (+ bias) in front of a batch-statistics BatchNorm.  No residual / ReLU / mask here (they
       // follow the normalisation); instead the per-row sum and sum of squares of the stored values.  Row groups are the OUTER
@@ -593,7 +673,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
               const int rg = half * 8 + u;
               const int mr = mrow + (rg & 3) + 8 * (rg >> 2);
               rowok[u] = ragged ? (mr + 4 * lh < g.M) : (mr < g.M);
-              sh[u] = ep.shift ? buf_f32(rsh, rowok[u] ? (unsigned)(4 * lh) * 4u : kPoison, mr * 4) : 0.f;
+              sh[u] = s_shift[wm * WM + i * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh];    // 0 for rows past M / no bias
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -630,13 +710,17 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
       }
     }
     }
+#ifndef DASAC_EXP_NOPRIO
+    if (STREAMK) __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef DASAC_TRACE_TILES
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have been acknowledged
+    DASAC_STAMP(5);                                    // the epilogue's stores have been issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and acknowledged
     DASAC_STAMP(3);
     if (g_tile_trace && threadIdx.x == 0) g_tile_trace[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;
 #endif
     if (STREAMK) __syncthreads();      // LDS is reused by the next tile of this worker
-  }
+  } while (STREAMK && it < it_end);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ PKG = os.path.join(ROOT, "da-sac_amd")
 out = "/tmp/libdasac_trace.so"
 srcs = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
-                       "-DDASAC_TRACE_TILES", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-shared"] + srcs + ["-o", out],
+                       "-DDASAC_TRACE_TILES"] + os.environ.get("DASAC_TRACE_DEFS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-shared"] + srcs + ["-o", out],
                       stderr=subprocess.DEVNULL)
 os.environ["DASAC_LIB"] = out
 sys.path.insert(0, ROOT); sys.path.insert(0, PKG)
@@ -47,6 +47,7 @@ for c in np.unique(xcc):
     m = xcc == c
     base = t[m, 0].min()
     t[m, :4] -= base
+    t[m, 5] -= base
     spans.append(t[m, 3].max())
 tick = us / float(np.median(spans))
 st, ld, kl, ep = t[:, 0] * tick, (t[:, 1] - t[:, 0]) * tick, (t[:, 2] - t[:, 1]) * tick, (t[:, 3] - t[:, 2]) * tick
@@ -55,8 +56,10 @@ st, ld, kl, ep = t[:, 0] * tick, (t[:, 1] - t[:, 0]) * tick, (t[:, 2] - t[:, 1])
 life = (t[:, 3] - t[:, 0]).astype(np.float64)
 tick = (us * min(1024, len(t)) / len(t)) / life.mean()
 st, ld, kl, ep = t[:, 0] * tick, (t[:, 1] - t[:, 0]) * tick, (t[:, 2] - t[:, 1]) * tick, (t[:, 3] - t[:, 2]) * tick
+ep_issue, ep_ack = (t[:, 5] - t[:, 2]) * tick, (t[:, 3] - t[:, 5]) * tick      # round 5: loads + arithmetic + store issue | waiting for the acknowledgements
 print("{} {} B={} {}x{}: {} workgroups, launch {:.1f} us, {:.1f} TFLOP/s".format(name, mode, B, H, H, len(t), us, 2.0 * B * H * H * cout * spec.K / us / 1e6))
-for nm, v in (("prologue (first tile -> LDS)", ld), ("K loop", kl), ("epilogue (stores acknowledged)", ep), ("whole workgroup", ld + kl + ep)):
+for nm, v in (("prologue (first tile -> LDS)", ld), ("K loop", kl), ("epilogue (stores acknowledged)", ep), ("  of which: until stores issued", ep_issue),
+              ("  of which: waiting for acks", ep_ack), ("whole workgroup", ld + kl + ep)):
     print("  {:32s} mean {:7.2f}  p10 {:7.2f}  p50 {:7.2f}  p90 {:7.2f}  max {:7.2f} us".format(nm, v.mean(), *np.percentile(v, [10, 50, 90]), v.max()))
 print("  sum over workgroups / (launch x 1024 slots): prologue {:.3f}  K loop {:.3f}  epilogue {:.3f}".format(
     ld.sum() / (us * 1024), kl.sum() / (us * 1024), ep.sum() / (us * 1024)))
