@@ -1530,6 +1530,12 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
                 "conv_gemm: bit masks index the GEMM's own pixel axis (ostride must be 1)");
   DASAC_REQUIRE(!relu_bits_out || relu, "conv_gemm: relu_bits_out records the pattern of a ReLU epilogue");
   DASAC_REQUIRE(!(x3 && (mask_bits || relu_bits_out)), "conv_gemm_x3: bit masks are implemented for the fp32 kernel only");
+  DASAC_REQUIRE(!stats || (!res && !relu), "conv_gemm_stats: the statistics epilogue stores the raw convolution (+ shift): no residual, no ReLU");
+  // plain 1x1 stride-1 convolution with a short contraction over the whole pixel range: the M-sweep kernel (bit-identical)
+  if (!x3 && !stats && !mask && schedule == 0 && K == Cx && stride == 1 && ostride == 1 && OH == H && OW == W && OutH == OH &&
+      OutW == OW && pix_begin == 0 && (pix_count <= 0 || pix_count == Nb * OH * OW) && (int64_t)Nb * OH * OW < (1ll << 31) &&
+      dasac_gemm1x1_msweep_ok(M, K))
+    return dasac_gemm1x1_msweep(x, packed, out, Nb, K, H * W, M, shift, res, mask_bits, relu_bits_out, relu, stream);
   GemmGeom g;
   const int Mpad = dasac_conv_mpad(M), Kloop = (K + kBK - 1) / kBK * kBK;   // table/pack are padded to 128 >= Kloop
   int rc = fill_geom(g, Nb, Cx, H, W, OH, OW, stride, M, Mpad, Kloop, OutH, OutW, ostride);

@@ -23,6 +23,8 @@ PROTOTYPES = {
     "dasac_relu_bits_words": (_sz, [_i, _l]),
     "dasac_conv_gemm_bits_ok": (_i, [_i, _i]),
     "dasac_conv_gemm": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "dasac_gemm1x1_msweep_ok": (_i, [_i, _i]),
+    "dasac_gemm1x1_msweep": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "dasac_conv_gemm_x3": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "dasac_conv_pack_x3": (_i, [_p, _i, _i, _p, _p]),
     "dasac_conv_gemm_workspace": (_sz, []),

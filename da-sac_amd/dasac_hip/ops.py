@@ -197,10 +197,12 @@ def tile_stats_buffer(Nb, M, OH, OW, device):
 
 
 def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=None, res=None, mask=None, relu=False, bits_out=None,
-              stats=None):
+              stats=None, schedule=None):
     """out[n,m,oh*os,ow*os] = epilogue(sum_k packed[k][m] * gather(x)); see dasac_conv_gemm.
     mask: fp32 activation (zero where <= 0) or a ReluBits of the output's shape; bits_out: ReluBits to fill (relu only);
-    stats: `tile_stats_buffer` to fill with per-tile channel sums / sums of squares of the output (dasac_conv_gemm_stats)."""
+    stats: `tile_stats_buffer` to fill with per-tile channel sums / sums of squares of the output (dasac_conv_gemm_stats).
+    schedule: None = the library's choice (M-sweep kernel for the short-K 1x1 layers, hybrid tile-per-block + stream-K for long-K
+    layers with a ragged last round, ...); 1 / 2 force one block per tile / the persistent stream-K kernel (tests, tools)."""
     lib = L.load()
     L.require_gpu(x, packed, table, out)
     Nb, Cx, H, W = x.shape
@@ -238,6 +240,13 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
                        pix_begin, pix_count, schedule, L.ptr(ws), 0 if ws is None else ws.numel(),
                        L.stream_ptr()), "dasac_conv_gemm")
 
+    if schedule is not None:
+        launch("conv_gemm<stream-K>" if schedule == 2 else "conv_gemm<tile-per-block>", 0, 0, int(schedule))
+        return out
+    if (stats is None and mask is None and fn is lib.dasac_conv_gemm and K == Cx and stride == 1 and ostride == 1 and (OH, OW) == (H, W)
+            and lib.dasac_gemm1x1_msweep_ok(M, K)):
+        launch("gemm1x1_msweep", 0, 0, 0)       # dasac_conv_gemm routes this call to the M-sweep kernel (same arguments, same bits)
+        return out
     lead = lib.dasac_conv_gemm_plan(Nb, OH, OW, M, K)
     if lead > 0:        # whole rounds one block per tile (lockstep over K: halo rows shared in L2), the rest stream-K
         launch("conv_gemm<tile-per-block>", 0, lead, 1)
