@@ -1,10 +1,12 @@
-"""Register / scratch budget of the four hot GEMM instantiations (VERDICT r1 #6b): cross-compiles conv_igemm.hip to gfx950
-assembly (no GPU needed, ~10 s) and checks that
-  * the tile-per-block forward/dgrad kernel stays at <= 128 VGPRs (4 waves per SIMD) and the persistent stream-K variant and
-    the weight-gradient kernel at <= 168 (3 waves per SIMD),
-  * NO scratch (spill) instruction sits between the first and the last MFMA of any of them -- i.e. inside the K loop; the few
-    spilled values of the forward kernel (tile-index bookkeeping) are written in the prologue and re-read in the epilogue,
-    those of the stream-K variant sit around the tile hand-off."""
+"""Register / scratch / instruction budget of the hot GEMM kernels: cross-compiles the GEMM sources to gfx950 assembly (no GPU
+needed, ~40 s) and checks that
+  * the tile-per-block forward/dgrad kernel stays at <= 128 VGPRs (4 waves per SIMD), the persistent stream-K variant and the
+    weight-gradient kernel at <= 168 (3 waves per SIMD), the M-sweep kernel at <= 256 (2 waves per SIMD),
+  * NO scratch (spill) instruction and no SGPR spill (v_readlane / v_writelane) sits inside a K loop -- the spilled values of the
+    forward kernel (tile bookkeeping) are written in the prologue and re-read in the epilogue,
+  * the K loop keeps its round-5 INSTRUCTION DIET: on this part every non-MFMA instruction a SIMD executes costs matrix-pipe
+    time (profiles/r5_mfma_partner_probe.txt), so the number of non-MFMA instructions per 32 MFMAs of the hot loop is a budget:
+    <= 34 for single-tap (1x1) contractions, <= 46 for multi-tap ones (round 4 carried 73)."""
 import os
 import re
 import shutil
@@ -14,39 +16,73 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# name fragment -> (VGPR budget, scratch bytes budget, non-MFMA instructions per 32 MFMAs in the hot loop or None)
 HOT = {
-    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi0EEE": 128,      # <128,128,2,16,FAST,tile-per-block,fp32>
-    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi0EEE": 168,      # stream-K
-    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi1EEE": 128,      # tile-per-block, ReLU epilogue records its bit mask
-    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi1EEE": 168,
-    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi2EEE": 128,      # tile-per-block, epilogue masks with a recorded bit mask
-    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi2EEE": 168,
-    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb0EEE": 168,
-    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb1EEE": 168,        # QUAD: four pixels per lane (1x1 stride-1 layers)
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi0ELb0EEE": (128, 320, 46),   # <128,128,2,16,FAST,tile-per-block,fp32>, multi-tap
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi0ELb1EEE": (128, 320, 34),   # same, single tap (1x1 layers)
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi0ELb0EEE": (168, 192, None),  # stream-K
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi0ELb1EEE": (168, 192, None),
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi1ELb0EEE": (128, 320, 46),   # ReLU epilogue records its bit mask
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi1ELb1EEE": (128, 320, 34),
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi2ELb0EEE": (128, 320, 46),   # epilogue masks with a recorded bit mask
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb0ELb0ELi2ELb1EEE": (128, 320, 34),
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi1ELb0EEE": (168, 192, None),
+    "conv_gemmILi128ELi128ELi2ELi16ELb1ELb1ELb0ELi2ELb0EEE": (168, 192, None),
+    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb0EEE": (168, 64, None),
+    "conv_wgradILi128ELi128ELi2ELb1ELb0ELb1EEE": (168, 64, None),             # QUAD: four pixels per lane (1x1 stride-1 layers)
+    "gemm1x1_msweepILi256ELi2ELi0EEE": (256, 160, None),                       # M-sweep: K = 256, 64-row blocks
+    "gemm1x1_msweepILi256ELi2ELi1EEE": (256, 160, None),
+    "gemm1x1_msweepILi256ELi2ELi2EEE": (256, 160, None),
 }
 
 
-@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.isfile(HIPCC), reason="hipcc not available")
-def test_hot_gemm_loops_have_no_scratch_and_fit_their_occupancy(tmp_path):
-    out = tmp_path / "conv_igemm.s"
+def _asm(tmp_path, src):
+    out = tmp_path / (src + ".s")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "da-sac_amd", "csrc"), "-S", "--cuda-device-only",
-                           "-o", str(out), os.path.join(ROOT, "da-sac_amd", "csrc", "conv_igemm.hip")], stderr=subprocess.DEVNULL)
-    txt = out.read_text()
+                           "-o", str(out), os.path.join(ROOT, "da-sac_amd", "csrc", src + ".hip")], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _loops(lines):
+    """(header, back edge, #MFMA) of every loop whose back edge is a branch to its own header label"""
+    found = []
+    for h, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m or "Loop Header" not in l:
+            continue
+        for j in range(h + 1, len(lines)):
+            if re.match(r"^\s*s_c?branch\S*\s+" + re.escape(m.group(1)) + r"\s*$", lines[j]):
+                found.append((h, j, sum("v_mfma" in x for x in lines[h:j + 1])))
+                break
+    return found
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.isfile(HIPCC), reason="hipcc not available")
+def test_hot_gemm_loops_have_no_scratch_fit_their_occupancy_and_keep_their_instruction_diet(tmp_path):
+    txt = _asm(tmp_path, "conv_igemm") + _asm(tmp_path, "gemm1x1_msweep")
     meta = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(
         r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size: (\d+)\n(?:.*\n){0,8}?\s+\.vgpr_count:\s+(\d+)", txt)}
-    for key, budget in HOT.items():
+    for key, (vgpr_budget, scratch_budget, diet) in HOT.items():
         names = [n for n in meta if key in n]
         assert len(names) == 1, (key, names)
         scratch, vgprs = meta[names[0]]
-        assert vgprs <= budget, (key, vgprs)
+        assert vgprs <= vgpr_budget, (key, vgprs)
+        assert scratch <= scratch_budget, (key, scratch)
         body = txt[txt.index("\n" + names[0] + ":"):]
         body = body[:body.index("s_endpgm")].split("\n")
         mfma = [i for i, l in enumerate(body) if "v_mfma" in l]
         assert len(mfma) >= 32
-        inside = [l.strip() for l in body[mfma[0]:mfma[-1]] if "scratch_" in l]
-        assert not inside, (key, inside[:3])
-        # bytes of scratch per lane.  The persistent stream-K variant may park up to 48 values around the tile hand-off (once per
-        # tile cut by a range boundary: half a deposit, 32 registers, is in flight next to the 64 accumulators); everything else
-        # keeps the round-1 budget of a few prologue values.
-        assert scratch <= (192 if "ELb1ELb1ELb0ELi" in key else 64), (key, scratch)
+        loops = [lp for lp in _loops(body) if lp[2] >= 16]
+        if loops:                                # every loop that carries MFMAs: no spill traffic of either kind
+            for h, j, _ in loops:
+                bad = [l.strip() for l in body[h:j + 1] if "scratch_" in l or "v_readlane" in l or "v_writelane" in l]
+                assert not bad, (key, bad[:3])
+        else:                                    # fully unrolled K loop (M-sweep): no scratch traffic between its first and last MFMA
+            bad = [l.strip() for l in body[mfma[0]:mfma[-1]] if "scratch_" in l]
+            assert not bad, (key, bad[:3])
+        if diet is not None:
+            h, j, n = max(loops, key=lambda lp: lp[2])
+            other = [l for l in body[h:j + 1] if l.strip() and not l.strip().startswith(";") and not re.match(r"^\.LBB", l.strip())
+                     and "v_mfma" not in l]
+            assert len(other) * 32.0 / n <= diet, (key, len(other), n)
