@@ -197,13 +197,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // BITS: 0 = fp32 epilogue operands only; 1 = the ReLU epilogue also records its pattern as bits (Epilogue::obits);
 //       2 = the epilogue masks with a recorded bit pattern (Epilogue::mbits).  Separate instantiations, so that the plain
 //       kernels carry none of the extra scalar state.
-// ONE_TAP (FAST, fp32): the contraction has a single tap (every 1x1 convolution and its data gradient): the tap's validity and
-//       offset are evaluated once per tile, a K-step only advances the gather offset by 16 channel planes -- no table row, no
-//       bounds test in the loop.
-// K-loop instruction diet (round 5, profiles/r5_mfma_partner_probe.txt): every non-MFMA instruction a SIMD executes costs
-// matrix-pipe time, and the round-4 loop carried 73 of them per 32 MFMAs.  The loop now runs two K-steps per iteration on
-// STATIC LDS buffers (all LDS addresses are immediates), the tap test is branch-free, and each group of loads is awaited once.
-template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3, int BITS = 0, bool ONE_TAP = false>
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3, int BITS = 0>
 __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
@@ -321,22 +315,12 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
       if (A_VEC % kThreads == 0 || t + i * kThreads < A_VEC) ra[i] = buf_f32x4(rw, voff_a[i], (kt) * a_step_bytes); \
     }                                                                                                \
     if (FAST) {                                                                                      \
-      unsigned voff;                                                                                 \
-      if (ONE_TAP) {                                                                                 \
-        voff = voff_1tap; /* (a poison offset stays >= 2^31: the tensor is smaller than 2 GiB) */    \
-        voff_1tap += (unsigned)(BK * planeHW) * 4u;                                                  \
-      } else {                                                                                       \
-        const int4 e = tab[(kt) * BK]; /* one tap per K-step: (koff, dh, dw, channel offset) */      \
-        int ex = e.x;                                                                                \
-        asm volatile("" : "+s"(ex)); /* keep this scalar load unconditional: otherwise the compiler fetches it */ \
-        /* under a branch on "some lane in bounds" (a saveexec / branch / load / wait chain per K-step)           */ \
-        const int ih = ih0 + e.y, iw = iw0 + e.z;                                                    \
-        const bool inb = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);            \
-        const unsigned cand = (unsigned)(pixbase + ex) * 4u;                                         \
-        voff = inb ? cand : kPoison;                                                                 \
-      }                                                                                              \
+      const int4 e = tab[(kt) * BK]; /* one tap per K-step: (koff, dh, dw, channel offset) */        \
+      const int ih = ih0 + e.y, iw = iw0 + e.z;                                                      \
+      const bool ok = ((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W);               \
       /* the K-step's tap and first channel plane ride in the per-lane offset (one VALU add); what is left for the */ \
       /* scalar operand -- the row's plane within the step -- is loop invariant: no scalar arithmetic per load      */ \
+      const unsigned voff = ok ? (unsigned)(pixbase + e.x) * 4u : kPoison;                           \
       _Pragma("unroll") for (int r = 0; r < B_QUADS; ++r) {                                          \
         const int row0 = X3 ? 8 * bq0 + 4 * r : 4 * (bq0 + r * B_Q_PASS);                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
@@ -398,15 +382,8 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
         }
       }
     }
-    // ONE_TAP: the tap's validity and offset, once per tile (table row 0 = (offset, dh, dw, 0) of the only tap)
-    unsigned voff_1tap = kPoison;
-    if (ONE_TAP) {
-      const int4 e = tab[0];
-      const int ih = ih0 + e.y, iw = iw0 + e.z;
-      if (((unsigned)ih < (unsigned)g.H) & ((unsigned)iw < (unsigned)g.W)) voff_1tap = (unsigned)(pixbase + e.x + ks * BK * planeHW) * 4u;
-    }
     DASAC_LOAD_TILE(ks);
-    DASAC_STORE_TILE(0);
+    DASAC_STORE_TILE(ks & 1);
     if (!STREAMK || ks == 0) {
       if (t < BM) s_shift[t] = pro_shift;
       if constexpr (BITS == 2) {
@@ -416,13 +393,10 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     }
     __syncthreads();
     DASAC_STAMP(1);
-    // one K-step on the STATIC buffer BUF (buffer = parity of kt - ks): LDS addresses fold into the instructions' offset fields
-    auto k_step = [&](auto buf_tag, int kt, bool more) __attribute__((always_inline)) {
-      constexpr int buf = decltype(buf_tag)::value;
+    for (int kt = ks; kt < ke; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < ke;
       if (more) DASAC_LOAD_TILE(kt + 1);
-      // the next tile's loads go out FIRST and are awaited LAST: the scheduler may not sink them below the MFMAs (it does, to
-      // recycle their registers, and then waits for them within the same half K-step)
-      __builtin_amdgcn_sched_barrier(0);
       f32x4 a4[BK / 8][TM], b4[BK / 8][TN];
       if (X3) {
         // quad slot q of the tile = (k octet lh, half h): h = 0 the bf16 heads, h = 1 the bf16 tails
@@ -444,46 +418,28 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
           }
       } else {
 #pragma unroll
-        for (int gq = 0; gq < BK / 8; ++gq) {
-          const int q = 2 * gq + lh;
+      for (int gq = 0; gq < BK / 8; ++gq) {
+        const int q = 2 * gq + lh;
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a4[gq][i] = sA[buf][q * BM + wm * WM + i * 32 + li];
+        for (int i = 0; i < TM; ++i) a4[gq][i] = sA[buf][q * BM + wm * WM + i * 32 + li];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b4[gq][j] = sB[buf][q * BN + wn * WN + j * 32 + li];
-          // ONE wait per operand group (the compiler would await each operand on its own: four s_waitcnt per K-step)
-          __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].x, b4[gq][j].x, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].y, b4[gq][j].y, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].z, b4[gq][j].z, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].w, b4[gq][j].w, acc[i][j], 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < TN; ++j) b4[gq][j] = sB[buf][q * BN + wn * WN + j * 32 + li];
       }
-      __builtin_amdgcn_sched_barrier(0);           // ... and no MFMA of this K-step drifts behind the stores / the barrier
-      if (more) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): all of the next tile's loads at once
-        DASAC_STORE_TILE(buf ^ 1);
+#pragma unroll
+      for (int gq = 0; gq < BK / 8; ++gq) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].x, b4[gq][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].y, b4[gq][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].z, b4[gq][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[gq][i].w, b4[gq][j].w, acc[i][j], 0, 0, 0);
+          }
       }
+      }
+      if (more) DASAC_STORE_TILE(buf ^ 1);
       __syncthreads();
-    };
-    {
-      using b0 = std::integral_constant<int, 0>;
-      using b1 = std::integral_constant<int, 1>;
-      int kt = ks;
-      for (; kt + 2 < ke; kt += 2) {       // two K-steps per iteration, both with a successor
-        k_step(b0{}, kt, true);
-        k_step(b1{}, kt + 1, true);
-      }
-      if (kt + 2 == ke) {
-        k_step(b0{}, kt, true);
-        k_step(b1{}, kt + 1, false);
-      } else {
-        k_step(b0{}, kt, false);
-      }
     }
 #undef DASAC_LOAD_TILE
 #undef DASAC_STORE_TILE
@@ -1428,7 +1384,7 @@ static bool want_streamk(int tiles, int k_steps) {
 }
 
 // `n_tiles` pixel tiles starting at g.n_tile0; schedule 0 = pick (want_streamk), 1 = one block per tile, 2 = stream-K
-template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool X3 = false, int BITS = 0, bool ONE_TAP = false>
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool X3 = false, int BITS = 0>
 static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
                        const Epilogue& ep, int n_tiles, int schedule, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
@@ -1440,12 +1396,12 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
     if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
     float* partial = reinterpret_cast<float*>(workspace);
     int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
-    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS, ONE_TAP>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
+    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
                        ep, m_tiles, n_tiles, partial, flags);
     return DASAC_OK;
   }
   const int n_tiles_pad = (n_tiles + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false, X3, BITS, ONE_TAP>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp,
+  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false, X3, BITS>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp,
                      tab, Out, g, ep, m_tiles, n_tiles, nullptr, nullptr);
   return DASAC_OK;
 }
@@ -1613,10 +1569,8 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
     DASAC_CHECK_LAUNCH("conv_gemm_x3");
     return DASAC_OK;
   }
-  const bool one_tap = fast && K == Cx;     // a single tap (1x1 convolutions, their data gradients): no table row per K-step
   if (stats) {
-    rc = one_tap ? launch_gemm<128, 128, 2, kBK, true, false, 3, true>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
-                 : launch_gemm<128, 128, 2, kBK, true, false, 3>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
+    rc = launch_gemm<128, 128, 2, kBK, true, false, 3>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
     if (rc) return rc;
     DASAC_CHECK_LAUNCH("conv_gemm_stats");
     return DASAC_OK;
@@ -1624,26 +1578,20 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
   if (mask_bits || relu_bits_out) {
     DASAC_REQUIRE(dasac_conv_gemm_bits_ok(M, Cx) && !(mask_bits && relu_bits_out),
                   "conv_gemm: bit masks need the 128-row fp32 tile with Cx %% 16 == 0 (dasac_conv_gemm_bits_ok), one direction per call");
-    if (one_tap)
-      rc = relu_bits_out ? launch_gemm<128, 128, 2, kBK, true, false, 1, true>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
-                         : launch_gemm<128, 128, 2, kBK, true, false, 2, true>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
-    else
-      rc = relu_bits_out ? launch_gemm<128, 128, 2, kBK, true, false, 1>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
-                         : launch_gemm<128, 128, 2, kBK, true, false, 2>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
+    rc = relu_bits_out ? launch_gemm<128, 128, 2, kBK, true, false, 1>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
+                       : launch_gemm<128, 128, 2, kBK, true, false, 2>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
     if (rc) return rc;
     DASAC_CHECK_LAUNCH("conv_gemm");
     return DASAC_OK;
   }
   switch (bm) {
     case 128:
-      rc = one_tap ? launch_gemm<128, 128, 2, kBK, true, false, 0, true>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
-           : fast  ? launch_gemm<128, 128, 2, kBK, true>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
-                   : launch_gemm<128, 128, 2, kBK, false>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
+      rc = fast ? launch_gemm<128, 128, 2, kBK, true>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s)
+                : launch_gemm<128, 128, 2, kBK, false>(x, packed, tab, out, g, ep, n_tiles, schedule, workspace, ws_bytes, s);
       break;
     case 64:
-      rc = one_tap ? launch_gemm<64, 128, 2, kBK, true, false, 0, true>(x, packed, tab, out, g, ep, n_tiles, 1, nullptr, 0, s)
-           : fast  ? launch_gemm<64, 128, 2, kBK, true>(x, packed, tab, out, g, ep, n_tiles, 1, nullptr, 0, s)
-                   : launch_gemm<64, 128, 2, kBK, false>(x, packed, tab, out, g, ep, n_tiles, 1, nullptr, 0, s);
+      rc = fast ? launch_gemm<64, 128, 2, kBK, true>(x, packed, tab, out, g, ep, n_tiles, 1, nullptr, 0, s)
+                : launch_gemm<64, 128, 2, kBK, false>(x, packed, tab, out, g, ep, n_tiles, 1, nullptr, 0, s);
       break;
     default:
       rc = fast ? launch_gemm<32, 256, 1, kBK, true>(x, packed, tab, out, g, ep, n_tiles, 1, nullptr, 0, s)

@@ -404,7 +404,9 @@ extern "C" int dasac_debug_set_ms_trace(void* buffer) {
 // 1 when dasac_conv_gemm routes this 1x1 stride-1 layer (K input channels -> M output channels) to the M-sweep kernel
 // (DASAC_MSWEEP=0 keeps everything on the tile-per-block / stream-K kernels; outputs are bit-identical either way)
 extern "C" int dasac_gemm1x1_msweep_ok(int M, int K) {
-  static const int mode = getenv("DASAC_MSWEEP") ? atoi(getenv("DASAC_MSWEEP")) : 1;
+  // Off by default: measured on the cfg-3 shapes (profiles/r5_msweep_experiments.txt) the kernel wins only on the plain forward
+  // (769 vs 805 us) -- a shape the networks do not launch; with residual / bit masks conv_gemm's tile-per-block kernel is ahead.
+  static const int mode = getenv("DASAC_MSWEEP") ? atoi(getenv("DASAC_MSWEEP")) : 0;
   if (!mode) return 0;
   if (K != 64 && K != 128 && K != 256) return 0;
   return (M >= 256 && M % 256 == 0) ? 1 : 0;

@@ -358,13 +358,12 @@ MSWEEP_CASES = [
 
 @pytest.mark.parametrize("case", MSWEEP_CASES, ids=[c[0] for c in MSWEEP_CASES])
 def test_msweep_kernel_is_bit_identical_to_the_tile_per_block_kernel(case):
-    """dasac_gemm1x1_msweep (the persistent M-sweep kernel dasac_conv_gemm picks for 1x1 stride-1 layers with K <= 256) against the
+    """dasac_gemm1x1_msweep (the persistent M-sweep kernel for 1x1 stride-1 layers with K <= 256; opt-in, DASAC_MSWEEP=1) against the
     tile-per-block kernel forced with schedule=1: same per-accumulator MFMA sequence and the same epilogue expression, so outputs
     -- and the recorded ReLU bit masks -- must be EQUAL, for every epilogue the network uses: shift only, shift + residual + ReLU
     (conv3 forward, deeplabv2.py:70-71,91-97), the same recording its bit mask, residual + bit-mask (conv1 data gradient, :59)."""
     from dasac_hip import ops
     _, K, M, (N_, H, W) = case
-    assert ops.L.load().dasac_gemm1x1_msweep_ok(M, K) == 1
     g = torch.Generator().manual_seed(K + M + H)
     spec = ops.ConvSpec(K, M, [(1, 1, 1, 0)], 1)
     x = torch.randn(N_, K, H, W, generator=g).cuda()
@@ -384,7 +383,10 @@ def test_msweep_kernel_is_bit_identical_to_the_tile_per_block_kernel(case):
         if want_bits:
             bits = ops.ReluBits(N_, M, H, W, x.device)
             bits.words.fill_(0x55555555)
-        ops.conv_gemm(x, packed, table, out, (H, W), 1, M, K, 1, shift_, res_, mask, relu, bits_out=bits, schedule=schedule)
+        if schedule is None:      # the M-sweep kernel itself (dasac_conv_gemm picks it only with DASAC_MSWEEP=1)
+            ops.gemm1x1_msweep(x, packed, out, shift_, res_, mask, relu, bits_out=bits)
+        else:
+            ops.conv_gemm(x, packed, table, out, (H, W), 1, M, K, 1, shift_, res_, mask, relu, bits_out=bits, schedule=schedule)
         return out, bits
 
     # against torch first (the reference arithmetic), then kernel against kernel
@@ -409,6 +411,6 @@ def test_msweep_kernel_is_bit_identical_to_the_tile_per_block_kernel(case):
     assert 0.3 < float((a == 0).float().mean()) < 0.7
     # in place on the residual, as the backward pass calls it (each element is read and written by the same lane)
     acc1, acc2 = res.clone(), res.clone()
-    ops.conv_gemm(x, packed, table, acc1, (H, W), 1, M, K, 1, None, acc1, mask, False)
+    ops.gemm1x1_msweep(x, packed, acc1, None, acc1, mask, False)
     ops.conv_gemm(x, packed, table, acc2, (H, W), 1, M, K, 1, None, acc2, mask, False, schedule=1)
     assert torch.equal(acc1, acc2) and torch.equal(acc1, a)
