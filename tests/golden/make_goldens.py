@@ -618,10 +618,48 @@ def g14_jaccard():
     save("g14_jaccard", **rec)
 
 
+def g15_inference():
+    """infer_val.py:160-166 + the result writer's label maps (:78-88): `_, logits = model(image)` ends in deeplabv2.py:217
+    `F.interpolate(logits, orig_size, mode="bilinear", align_corners=True)`, then `F.softmax(logits, 1)`, `np.argmax(masks_raw, 0)
+    .astype(np.uint8)` and `convert_to_cs` (:62-67) over `tools.category.labels`.  infer_val.py itself cannot be imported here
+    (imageio is absent), so the generator compiles the reference's OWN `convert_to_cs` function definition out of its source
+    file and binds it to the reference's own label table; the three ATen / numpy call lines are restated verbatim.  Stored:
+    low-resolution logits, the train-id and label-id maps, the winning probability and the train id -> label id table that
+    `convert_to_cs` realises for ids 0..18."""
+    import ast
+    from tools.category import labels as CS_LABELS            # reference
+    src = open("/root/reference/infer_val.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "convert_to_cs"]
+    assert len(fn) == 1
+    ns = {"np": np, "CS_LABELS": CS_LABELS}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "/root/reference/infer_val.py", "exec"), ns)
+    convert_to_cs = ns["convert_to_cs"]
+    g = torch.Generator().manual_seed(15)
+    rec = {}
+    for name, (B, C, h, w, H, W) in dict(a=(2, 19, 23, 31, 177, 241), b=(1, 19, 33, 65, 257, 513)).items():
+        logits_low = torch.randn(B, C, h, w, generator=g) * 3
+        logits = F.interpolate(logits_low, (H, W), mode="bilinear", align_corners=True)         # deeplabv2.py:217
+        masks_pred = F.softmax(logits, 1)                                                        # infer_val.py:162
+        preds, preds_cs = [], []
+        for i in range(B):
+            masks_raw = masks_pred[i].cpu().numpy()                                              # :80
+            pred = np.argmax(masks_raw, 0).astype(np.uint8)                                      # :81
+            preds.append(pred)
+            preds_cs.append(convert_to_cs(pred))                                                 # :86
+        top2 = masks_pred.topk(2, dim=1).values
+        rec.update({"logits_" + name: logits_low.numpy(), "size_" + name: np.array([H, W]), "pred_" + name: np.stack(preds),
+                    "pred_cs_" + name: np.stack(preds_cs), "conf_" + name: top2[:, 0].numpy().astype(np.float16),
+                    # pixels whose two best classes are closer than 1e-4 (fp32 noise of another upsampling order may flip them)
+                    "tie_" + name: np.packbits((top2[:, 0] - top2[:, 1]).numpy() < 1e-4)})
+    lut = convert_to_cs(np.arange(19, dtype=np.uint8))
+    print("g15: train id -> label id", lut.tolist())
+    save("g15_inference", lut=lut, **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g3", "g4", "g5", "g6", "g7", "g2", "g10", "g8", "keys", "g11", "g12", "g13", "g14", "g15"]
     table = dict(g3=g3_bilinear, g4=g4_refine, g5=g5_pseudo_labels, g6=g6_losses, g7=g7_state_sequences,
                  g2=g2_resnet, g10=g10_vgg, g8=g8_two_steps, keys=keys_fixture, g11=g11_index_tables, g12=g12_views,
-                 g13=g13_photometric, g14=g14_jaccard)
+                 g13=g13_photometric, g14=g14_jaccard, g15=g15_inference)
     for w in which:
         table[w]()

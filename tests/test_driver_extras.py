@@ -165,3 +165,52 @@ def test_train_epoch_policy(monkeypatch):
     calls.clear()
     driver.train_epoch(None, None, src[:2], tgt[:2], NS(**dict(DEFAULT_CFG, BASELINE=True)), 1)
     assert calls == [("base", ("s0",), "t0"), ("base", ("s1",), "t1")]
+
+
+def _g15():
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g15_inference.npz"))
+
+
+def _g15_case(g, name):
+    import numpy as np
+    logits = torch.from_numpy(g["logits_" + name])
+    H, W = (int(v) for v in g["size_" + name])
+    n = logits.shape[0] * H * W
+    tie = torch.from_numpy(np.unpackbits(g["tie_" + name])[:n].astype(bool)).view(logits.shape[0], H, W)
+    return logits, H, W, torch.from_numpy(g["pred_" + name]), torch.from_numpy(g["pred_cs_" + name]), torch.from_numpy(g["conf_" + name].astype("float32")), tie
+
+
+def test_inference_oracle_and_label_table_match_the_reference_golden_g15():
+    """Golden g15 = the reference's own inference path (infer_val.py:160-166, :78-88 and ITS `convert_to_cs` over
+    `tools.category.labels`, captured by tests/golden/make_goldens.py): pins the hard-coded train id -> label id table of
+    driver.py and oracle.head_ref.infer_labels, which the GPU test of the fused kernel is compared with."""
+    import driver
+    from oracle import head_ref as R
+    g = _g15()
+    assert tuple(int(v) for v in g["lut"]) == tuple(driver.CITYSCAPES_TRAIN_TO_ID)
+    lut = torch.tensor(driver.CITYSCAPES_TRAIN_TO_ID, dtype=torch.uint8)
+    for name in ("a", "b"):
+        logits, H, W, pred, pred_cs, conf, tie = _g15_case(g, name)
+        lab, c, gap = R.infer_labels(logits, H, W)
+        assert torch.equal(lab[~tie], pred[~tie]) and float((lab != pred).float().mean()) < 1e-4
+        lab_cs, _, _ = R.infer_labels(logits, H, W, lut)
+        assert torch.equal(lab_cs[~tie], pred_cs[~tie])
+        assert float((c - conf).abs().max()) < 1e-3          # (the golden stores the winning probability as fp16)
+
+
+@pytest.mark.gpu
+def test_fused_inference_kernel_matches_the_reference_golden_g15():
+    """dasac_infer_labels (upsample + softmax + argmax + id table in one kernel) against what the reference's inference path
+    wrote for the same logits (golden g15): identical label maps, both train ids and Cityscapes ids, outside exact near-ties."""
+    import driver
+    from dasac_hip import ops
+    g = _g15()
+    lut = torch.tensor(driver.CITYSCAPES_TRAIN_TO_ID, dtype=torch.uint8).cuda()
+    for name in ("a", "b"):
+        logits, H, W, pred, pred_cs, conf, tie = _g15_case(g, name)
+        lab, c = ops.infer_labels(logits.cuda(), (H, W), want_conf=True)
+        assert torch.equal(lab.cpu()[~tie], pred[~tie]) and float((lab.cpu() != pred).float().mean()) < 1e-4
+        lab_cs, _ = ops.infer_labels(logits.cuda(), (H, W), lut)
+        assert torch.equal(lab_cs.cpu()[~tie], pred_cs[~tie])
+        assert float((c.cpu() - conf).abs().max()) < 1e-3
