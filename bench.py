@@ -53,9 +53,19 @@ def model_cfg(arch="deeplabv2_resnet101", baseline=False):
 # ----------------------------------------------------------------------------------------------------------------
 # CPU baseline + full-resolution parity: ONE bounded sample of the workload, run by the oracle (timed) and by the HIP path
 # ----------------------------------------------------------------------------------------------------------------
-_PARITY_KEYS = ("model.conv1.weight", "model.layer1.0.conv1.weight", "model.layer2.3.bn2.weight", "model.layer3.10.conv2.weight",
-                "model.layer3.22.conv3.weight", "model.layer4.2.bn3.bias", "model.layer4.2.conv2.weight",
-                "model.layer5.conv2d_list.0.weight", "model.layer5.conv2d_list.3.bias")
+# (round 5: EVERY trainable tensor of the student is compared at full resolution, gradients and updated parameters -- 320 tensors for
+# ResNet-101; rounds 3-4 sampled nine)
+
+
+def csrc_sha1():
+    """Hash of the kernel sources (file names + contents of da-sac_amd/csrc): identifies what a PMC measurement was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "da-sac_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def _sample_inputs(size):
@@ -84,8 +94,8 @@ def cpu_sample(size):
     dt = time.time() - t0
     ref = {"loss_ce": ls["loss_ce"], "self_ce": lt["self_ce"], "teacher_diff": lt["teacher_diff"],
            "labels": outs["teacher_labels"], "running_conf": m.running_conf.clone(),
-           "grads": {k: m.student[k].grad.detach().clone() for k in _PARITY_KEYS},
-           "params": {k: m.student[k].detach().clone() for k in _PARITY_KEYS}}
+           "grads": {k: v.grad.detach().clone() for k, v in m.student.items() if getattr(v, "grad", None) is not None},
+           "params": {k: v.detach().clone() for k, v in m.student.items() if getattr(v, "grad", None) is not None}}
     return dt, cores, sd, ref
 
 
@@ -116,8 +126,8 @@ def hip_sample(size, sd, device, fuse=True):
     named = dict(net.backbone.named_parameters())
     return {"loss_ce": float(ls["loss_ce"]), "self_ce": float(lt["self_ce"]), "teacher_diff": float(lt["teacher_diff"]),
             "labels": outs["teacher_labels"].cpu(), "running_conf": net.running_conf.detach().cpu(),
-            "grads": {k: named[k].grad.detach().cpu() for k in _PARITY_KEYS},
-            "params": {k: named[k].detach().cpu() for k in _PARITY_KEYS}}
+            "grads": {k: v.grad.detach().cpu() for k, v in named.items() if v.grad is not None},
+            "params": {k: v.detach().cpu() for k, v in named.items() if v.grad is not None}}
 
 
 def compare_sample(ref, got):
@@ -125,13 +135,19 @@ def compare_sample(ref, got):
     tests/test_gpu_fullres.py bounds)."""
     rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
     tmax = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    keys = sorted(ref["grads"])
+    assert keys == sorted(got["grads"]), "the oracle and the HIP path differentiate different parameter sets"
+    g_err = {k: tmax(got["grads"][k], ref["grads"][k]) for k in keys}
+    p_err = {k: tmax(got["params"][k], ref["params"][k]) for k in keys}
+    g_worst, p_worst = max(keys, key=g_err.get), max(keys, key=p_err.get)
     return {"loss_ce_rel": rel(got["loss_ce"], ref["loss_ce"]), "self_ce_rel": rel(got["self_ce"], ref["self_ce"]),
             "label_mismatch_frac": float((got["labels"] != ref["labels"]).double().mean()),
             "labelled_frac": float((ref["labels"] != 255).double().mean()),
             "running_conf_max_abs": float((got["running_conf"] - ref["running_conf"]).abs().max()),
-            "grad_max_err_over_tensor_max": max(tmax(got["grads"][k], ref["grads"][k]) for k in _PARITY_KEYS),
-            "param_max_err_over_tensor_max": max(tmax(got["params"][k], ref["params"][k]) for k in _PARITY_KEYS),
-            "sampled_tensors": len(_PARITY_KEYS)}
+            "grad_max_err_over_tensor_max": g_err[g_worst], "grad_worst_tensor": g_worst,
+            "grad_median_err_over_tensor_max": sorted(g_err.values())[len(keys) // 2],
+            "param_max_err_over_tensor_max": p_err[p_worst], "param_worst_tensor": p_worst,
+            "sampled_tensors": len(keys)}
 
 
 def parity_fullres(size, device=None, sample=None, fuse=True):
@@ -343,6 +359,7 @@ def main():
     import models
     import driver
     from dasac_hip import ops
+    from dasac_hip import lib as L_
     from dasac_hip.parallel import OverlappedDataParallel
 
     cfg = model_cfg(arch, baseline)
@@ -389,13 +406,25 @@ def main():
         fence()
         if instrumented:
             ops.PROFILE.start()
+        timed_wrapper = step_net if hasattr(step_net, "time_exposed_reduction") else None
+        if timed_wrapper is not None:
+            timed_wrapper.time_exposed_reduction(True)
         t0 = time.perf_counter()
         for i in range(steps):
             res = step(first + warmup + i)
         fence()
         dt_ = time.perf_counter() - t0
         prof_ = ops.PROFILE.stop() if instrumented else None
+        # per rank: its own wall time over the K steps and the part of it its launch stream spent WAITING for gradient reductions
+        # at the end of the backward passes (the exposed, un-overlapped share) -- the first multi-GPU run explains its own curve
+        exposed = timed_wrapper.exposed_reduction_ms() if timed_wrapper is not None else 0.0
+        if timed_wrapper is not None:
+            timed_wrapper.time_exposed_reduction(False)
+        per_rank[:] = [{"rank": rank, "ms_per_step": round(dt_ / steps * 1e3, 3), "exposed_reduce_ms_per_step": round(exposed / steps, 3)}]
         if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, per_rank[0])
+            per_rank[:] = gathered
             tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_ = float(tmax)
@@ -416,8 +445,10 @@ def main():
         return out_
 
     ops.set_precision(args.precision)
+    per_rank = []
     # 1) the headline: K steps, nothing but the step itself inside the timed region
     dt, _, out = measure(0, args.warmup, args.steps, False)
+    per_rank_headline = list(per_rank)
     done = args.warmup + args.steps
     # 2) the same workload once more with a HIP event pair around every instrumented launch (kernel table / roofline)
     prof, dt_prof, psteps = {}, None, max(1, args.profile_steps)
@@ -462,7 +493,14 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-measured HBM bytes per launch (separate rocprofv3 passes)
         if os.path.isfile(tfile):
-            traffic = json.load(open(tfile)).get(dom_name)
+            blob = json.load(open(tfile))
+            # the counters were taken on a particular version of the kernels: tools/hbm_traffic.py stamps the file with the hash of
+            # csrc/, and a stale file is reported as such instead of silently describing kernels that no longer exist
+            if blob.get("csrc_sha1") == csrc_sha1():
+                traffic = blob.get(dom_name)
+            else:
+                traffic = {"stale": "profiles/traffic.json was measured on csrc {} but this tree is {}: re-run tools/profile_round.sh".format(
+                    str(blob.get("csrc_sha1"))[:12], csrc_sha1()[:12])}
         line = {
             "metric": "train images/sec (769x769, 19-cls, RN101 DeepLabv2, K=3)",
             "value": round(world * args.batch * args.steps / dt, 4), "unit": "images/sec", "n_gpus": world,
@@ -483,7 +521,8 @@ def main():
                                             if fused_now else "two passes (train.py:266-298 call order)"),
                        "distributed": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                                        "backend": dist.get_backend() if dist.is_initialized() else None, "wrapper": wrapper,
-                                       "ranks_per_gpu": per_gpu, "self_launched": os.environ.get("DASAC_BENCH_SELF_LAUNCHED") == "1"},
+                                       "ranks_per_gpu": per_gpu, "self_launched": os.environ.get("DASAC_BENCH_SELF_LAUNCHED") == "1",
+                                       "reserved_cus": L_.load().dasac_reserved_cus(), "per_rank": per_rank_headline},
                        # deviations from SURVEY 8d's synthetic recipe (same arithmetic work; the reference's SGD hyper-parameters
                        # diverge within a few steps on N(0,0.01) weights with random labels):
                        "synthetic_recipe": "weights He-normal (not N(0,.01)), BN gamma~U(.5,1.5)*{1,.1 closing a residual branch,.3 shortcut}, "

@@ -15,6 +15,11 @@ constexpr int kNumCu = 256;
 
 int fail(int code, const char* fmt, ...);   // records dasac_last_error(), returns code
 
+// CUs this process leaves to kernels that run BESIDE its own (RCCL's all-reduce kernels under the overlapped data-parallel
+// wrapper): 0 by default, a multiple of 8 (whole CUs per XCD); dasac_set_reserved_cus / DASAC_SK_RESERVE_CUS.  Sizes the
+// persistent stream-K grid and the grid cap of the streaming kernels.
+int reserved_cus();
+
 inline hipStream_t as_stream(dasac_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define DASAC_REQUIRE(cond, ...)                                        \
@@ -37,7 +42,8 @@ inline hipStream_t as_stream(dasac_stream_t s) { return reinterpret_cast<hipStre
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs several times over
-inline int stream_grid(int64_t work_items, int block, int max_blocks = kNumCu * 16) {
+inline int stream_grid(int64_t work_items, int block, int max_blocks = 0) {
+  if (max_blocks <= 0) max_blocks = (kNumCu - reserved_cus()) * 16;
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;
   if (g > max_blocks) g = max_blocks;

@@ -254,13 +254,19 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
   const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
   int it, it_end;                                            // (tile, K-step) space: tiles*KT < 2^31 (checked by the host)
   int my_range = 0;
-  long long sk_total = 0;
-  constexpr int G = kSkWorkers;                              // == gridDim.x of a stream-K launch; a constant divisor keeps the range arithmetic cheap
+  // stream-K ranges: G workers (= gridDim.x: 3 per CU on all CUs, or on fewer when CUs are left to overlapped collectives,
+  // dasac_set_reserved_cus) split the (tile, K-step) space into contiguous ranges of sk_per or sk_per + 1 steps
+  // (the first sk_rem ranges get the extra one): range r starts at r * sk_per + min(r, sk_rem)
+  int sk_per = 0, sk_rem = 0;
+  auto sk_start = [&](int r) { return r * sk_per + min(r, sk_rem); };
   if (STREAMK) {
+    const int G = gridDim.x;
     my_range = xcd * (G / kNumXcd) + slot;
-    sk_total = (long long)m_tiles * n_tiles * KT;
-    it = (int)(sk_total * my_range / G);
-    it_end = (int)(sk_total * (my_range + 1) / G);
+    const int sk_total = m_tiles * n_tiles * KT;             // < 2^31 (checked by the host)
+    sk_per = sk_total / G;
+    sk_rem = sk_total - sk_per * G;
+    it = sk_start(my_range);
+    it_end = sk_start(my_range + 1);
   } else {
     // each XCD owns a CONTIGUOUS run of pixel tiles (spatial neighbours share halo rows in its L2)
     const int per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
@@ -475,9 +481,9 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
         // I hold the FIRST K-steps; the rest was deposited by the following range(s), each at the very start of its work
         // (a range shorter than a tile -- fewer tiles than workers -- makes several of them contribute).  Ranges are never
         // empty (the host picks this schedule only with >= 1 K-step per worker).
-        const long long tile_end = (long long)(tile + 1) * KT;
+        const int tile_end = (tile + 1) * KT;
         int n_contrib = 1;                                     // contributors are my_range + 1 .. my_range + n_contrib
-        while (sk_total * (my_range + n_contrib + 1) / G < tile_end) ++n_contrib;
+        while (sk_start(my_range + n_contrib + 1) < tile_end) ++n_contrib;
         if (t == 0) {
           // Progress does not need all workers resident: a range deposits at the very START of its work, before it waits for
           // anything, and blocks are dispatched in id order, so the depositor of r is at worst the next block to get a slot.
@@ -1368,16 +1374,19 @@ static bool persistent_grid_fits() {
   return ok;
 }
 
+// workers of a persistent stream-K launch: 3 per CU on the CUs this process does not leave to overlapped collectives
+static int sk_workers() { return (kNumCu - reserved_cus()) * kSkWorkersPerCu; }
+
 static bool want_streamk(int tiles, int k_steps) {
   static const int mode = getenv("DASAC_STREAMK") ? atoi(getenv("DASAC_STREAMK")) : 1;   // 0 off, 1 auto, 2 always
   if (!persistent_grid_fits()) return false;
-  if (mode == 0 || (long long)tiles * k_steps < kSkWorkers) return false;               // every range gets >= 1 K-step
+  if (mode == 0 || (long long)tiles * k_steps < sk_workers()) return false;             // every range gets >= 1 K-step
   if (mode == 2) return true;
   // measured: the persistent schedule (3 workers/CU, <=168 registers) wins on long contractions whose tile count
   // fills the last round of the plain launch badly; short-K 1x1 layers are better off with the plain kernel's
   // 4 blocks per CU (128 registers) even with a partly empty last round (85 vs 99 TFLOP/s at K = 256) -- unless
   // the launch would leave most of the chip idle (small batches: 296 tiles at B = 2, 148 at B = 1).
-  const int resident = kNumCu * 3;
+  const int resident = (kNumCu - reserved_cus()) * 3;
   const int rounds = (tiles + resident - 1) / resident;
   const double eff = (double)tiles / ((double)rounds * resident);
   return k_steps >= 64 ? eff < 0.93 : (k_steps >= 16 && eff < 0.6);
@@ -1389,14 +1398,14 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
                        const Epilogue& ep, int n_tiles, int schedule, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
   if ((long long)m_tiles * (n_tiles + kNumXcd) * (g.Kpad / BK) >= (1ll << 31)) return fail(DASAC_EINVAL, "conv_gemm: iteration space exceeds 2^31");
-  const bool sk_ok = BM == 128 && workspace && (long long)m_tiles * n_tiles * (g.Kpad / BK) >= kSkWorkers && persistent_grid_fits();
+  const bool sk_ok = BM == 128 && workspace && (long long)m_tiles * n_tiles * (g.Kpad / BK) >= sk_workers() && persistent_grid_fits();
   if (sk_ok && (schedule == 2 || (schedule == 0 && want_streamk(m_tiles * n_tiles, g.Kpad / BK)))) {
     const size_t part_bytes = (size_t)kSkWorkers * (BM * BN) * sizeof(float);
     const size_t need = part_bytes + (size_t)(kSkWorkers + 1) * sizeof(int);
     if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
     float* partial = reinterpret_cast<float*>(workspace);
     int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
-    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS>), dim3(kSkWorkers), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
+    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS>), dim3(sk_workers()), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
                        ep, m_tiles, n_tiles, partial, flags);
     return DASAC_OK;
   }

@@ -14,6 +14,8 @@ PROTOTYPES = {
     "dasac_version": (_i, []),
     "dasac_last_error": (C.c_char_p, []),
     "dasac_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    "dasac_reserved_cus": (_i, []),
+    "dasac_set_reserved_cus": (_i, [_i]),
     "dasac_pseudo_labels_workspace": (_sz, [_i, _i, _l]),
     "dasac_pseudo_labels": (_i, [_p, _p, _p, _f, _f, _i, _i, _l, _p, _p, _p, _p, _sz, _p]),
     "dasac_conv_mpad": (_i, [_i]),

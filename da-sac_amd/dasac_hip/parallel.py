@@ -26,6 +26,8 @@ linear in it) and the buckets are SUM-reduced -- for power-of-two world sizes bi
 "divide, then sum", and it works on every backend (gloo has no AVG).
 Under stock DDP everything still works (tests/test_gpu_ddp.py); this wrapper is the fast path bench.py uses.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -47,6 +49,9 @@ class GradSink:
     """
 
     def __init__(self, process_group=None, bucket_bytes=32 << 20, reduce_single_rank=False):
+        self.time_exposed = False                 # bench: time the stream waits at the end of every backward pass
+        self._exposed_events = []
+        self._device = None
         self.pg = process_group
         self.bucket_bytes = int(bucket_bytes)
         self.reduce_single_rank = bool(reduce_single_rank)
@@ -150,10 +155,29 @@ class GradSink:
                             self.alloc(j).zero_()
                 self._launch(b, False)
         assert all(n == 1 for n in self._launches), "GradSink: a bucket was reduced {} times in one pass".format(self._launches)
+        # what the launch stream still has to wait for when the backward pass is over = the EXPOSED part of the reduction;
+        # timed with an event pair on that stream when asked for (bench.py --gpus N reports it per rank)
+        timed = self.time_exposed and self._works and self._device is not None and self._device.type == "cuda"
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()                               # nccl: the CURRENT STREAM waits (no host block); gloo: host wait
+        if timed:
+            ev[1].record()
+            self._exposed_events.append(ev)
         self._works = []
         self._flat = None                          # the views handed out keep the storage alive as long as needed
+
+
+def _exposed_ms(sink):
+    """Milliseconds the launch stream waited for outstanding reductions since the last call (synchronises the events)."""
+    total = 0.0
+    for a, b in sink._exposed_events:
+        b.synchronize()
+        total += a.elapsed_time(b)
+    sink._exposed_events = []
+    return total
 
 
 def _trainable_backbones(module):
@@ -183,6 +207,11 @@ class OverlappedDataParallel(nn.Module):
         self.module = module
         self.process_group = process_group
         self.broadcast_buffers = bool(broadcast_buffers)
+        # CUs left to the collective's kernels, which run beside the backward GEMMs: the persistent stream-K grid gives every worker
+        # the same matrix work, so a CU that also hosts RCCL workgroups finishes last.  8 by default under world > 1
+        # (DASAC_SK_RESERVE_CUS overrides, 0 = none); a single rank keeps the whole chip.
+        if self._world() > 1 and "DASAC_SK_RESERVE_CUS" not in os.environ:
+            L.load().dasac_set_reserved_cus(8)
         self._sinks = []
         for net in _trainable_backbones(module):
             sink = GradSink(process_group, int(bucket_mb) << 20, reduce_single_rank)
@@ -241,6 +270,15 @@ class OverlappedDataParallel(nn.Module):
             raise RuntimeError("OverlappedDataParallel: trainable parameters outside every engine plan would never be "
                                "all-reduced: {} (wrap the model in torch's DistributedDataParallel instead)".format(missing[:4]))
         self._covered = key
+
+    def time_exposed_reduction(self, on=True):
+        for sk in self._sinks:
+            sk.time_exposed = bool(on)
+            sk._exposed_events = []
+
+    def exposed_reduction_ms(self):
+        """Stream time spent waiting for gradient reductions at the end of the backward passes since the last call."""
+        return sum(_exposed_ms(sk) for sk in self._sinks)
 
     def forward(self, *args, **kwargs):
         self._check_coverage()

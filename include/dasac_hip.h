@@ -37,6 +37,14 @@ typedef void* dasac_stream_t; /* hipStream_t */
 int dasac_version(void);                 /* ABI version, currently 1 */
 const char* dasac_last_error(void);      /* thread-local message of the last failure */
 int dasac_device_info(int* cu_count, int* wave_size, char* arch, size_t arch_len);
+/* Compute units this process leaves to kernels that run beside its own -- RCCL's all-reduce kernels when the gradient
+ * reduction is overlapped with the backward pass (train.py:104 DistributedDataParallel; here dasac_hip.parallel).  The
+ * persistent stream-K grid (3 workers per CU, equal matrix work per worker) and the grid cap of the streaming kernels are
+ * sized to 256 - n CUs, so that a collective's workgroups do not land on CUs whose workers then finish last.  n is rounded
+ * up to a multiple of 8 and capped at 128; 0 (the default, or DASAC_SK_RESERVE_CUS in the environment) = the whole chip.
+ * dasac_set_reserved_cus returns the previous value.  Results do not depend on n beyond the summation order of stream-K tiles. */
+int dasac_reserved_cus(void);
+int dasac_set_reserved_cus(int n);
 
 /* ------------------------------------------------------------------------------------------
  * Pseudo-label extraction -- models/sac.py:154-187 (`SAC._pseudo_labels_probs`).

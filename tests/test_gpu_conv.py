@@ -414,3 +414,34 @@ def test_msweep_kernel_is_bit_identical_to_the_tile_per_block_kernel(case):
     ops.gemm1x1_msweep(x, packed, acc1, None, acc1, mask, False)
     ops.conv_gemm(x, packed, table, acc2, (H, W), 1, M, K, 1, None, acc2, mask, False, schedule=1)
     assert torch.equal(acc1, acc2) and torch.equal(acc1, a)
+
+
+def test_reserved_cus_shrink_the_persistent_grid_without_changing_results():
+    """dasac_set_reserved_cus(n): the stream-K grid (and the streaming kernels' grid cap) is sized to 256 - n CUs so that RCCL's
+    kernels, which the overlapped data-parallel wrapper runs beside the backward GEMMs, do not share CUs with workers that all
+    carry the same matrix work.  The partition of the (tile, K-step) space changes with the worker count, the result only in
+    the summation order of tiles cut by a range boundary."""
+    from dasac_hip import ops
+    lib = ops.L.load()
+    g = torch.Generator().manual_seed(5)
+    spec = ops.ConvSpec(256, 256, [(3, 3, 2, 2)], 1)
+    x = torch.randn(8, 256, 97, 97, generator=g).cuda()
+    w = (torch.randn(256, 256, 3, 3, generator=g) / 48.0).cuda()
+    order = ops.gemm_order(spec, False)
+    table, packed = ops.conv_table(spec, 97, 97, False, x.device, order), ops.conv_pack(spec, [w], False, None, order=order)
+    prev = lib.dasac_set_reserved_cus(0)
+    try:
+        outs = {}
+        for n in (0, 8, 16, 13):
+            lib.dasac_set_reserved_cus(n)
+            assert lib.dasac_reserved_cus() == (n + 7) // 8 * 8
+            y = torch.full((8, 256, 97, 97), float("nan"), device="cuda")
+            ops.conv_gemm(x, packed, table, y, (97, 97), 1, 256, spec.K, 1, None, None, None, False, schedule=2)
+            outs[n] = y
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=2, dilation=2).float()
+        for n, y in outs.items():
+            assert rel_err(y, ref) < 2e-6, n
+            assert float((y - outs[0]).abs().max()) <= 2e-6 * float(ref.abs().max()), n
+        assert torch.equal(outs[16], outs[13])                       # 13 rounds up to 16: the same grid, the same bits
+    finally:
+        lib.dasac_set_reserved_cus(prev)

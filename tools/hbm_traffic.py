@@ -77,4 +77,8 @@ for k in sorted(fc, key=lambda k: -fc[k][0]):
                         "tools/hbm_traffic.py): all template instantiations of the class, dispatches from the first label_pad_mask on; read side x2 "
                         "(FETCH_SIZE reports half of a coalesced stream on gfx950, WRITE_SIZE is exact: profiles/r2_pmc_calibration.md)"}
 if "--json" in sys.argv:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                      # csrc_sha1(): bench.py reports `traffic` only for the kernel sources it was measured on
+    out["csrc_sha1"] = bench.csrc_sha1()
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
