@@ -59,7 +59,7 @@ struct GemmGeom {
   int M, Mpad, Kpad;
   // output tensor [Nb, M, OutH, OutW]; element (oh*ostride, ow*ostride)
   int OutH, OutW, ostride;
-  int x_bytes, w_bytes, z_bytes, out_bytes;  // buffer-descriptor extents (gathered tensor, packed weights, dZ, output)
+  unsigned x_bytes, w_bytes, z_bytes, out_bytes;  // buffer-descriptor extents (gathered tensor, packed weights, dZ, output): < 4 GiB
 };
 
 struct Epilogue {
@@ -91,12 +91,16 @@ struct Epilogue {
 // poison offset 2^31 >= num_records) and moves the per-row part of the address (channel plane, K-step
 // of the weights) into the scalar operand -- the vector ALU, which shares issue bandwidth with the
 // matrix pipe (measured: ~6 matrix-pipe cycles lost per VALU instruction), stays almost idle.
-constexpr unsigned kPoison = 0x80000000u;
+// Offsets are UNSIGNED 32-bit byte offsets: a tensor may be up to 4 GiB - 4 KiB (round 5; rounds 1-4 kept them below 2^31 and
+// used 2^31 as the poison).  The poison is the largest offset: always >= num_records, whatever scalar offset is added (the
+// hardware compares the per-lane offset with num_records - soffset), and never combined with an instruction immediate.
+constexpr unsigned kPoison = 0xFFFFFFFFu;
+constexpr int64_t kMaxTensorBytes = (1ll << 32) - 4096;
 constexpr int kRsrcFlags = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family word 3)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, kRsrcFlags);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, kRsrcFlags);
 }
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -1339,18 +1343,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ P,
 static int fill_geom(GemmGeom& g, int Nb, int Cx, int H, int W, int OH, int OW, int stride, int M, int Mpad, int Kpad,
                      int OutH, int OutW, int ostride) {
   DASAC_REQUIRE(Nb > 0 && Cx > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && stride > 0 && M > 0, "conv: bad geometry");
-  DASAC_REQUIRE((int64_t)Nb * Cx * H * W < (1ll << 31) && (int64_t)Nb * M * OutH * OutW < (1ll << 31) &&
-                    (int64_t)Nb * OH * OW < (1ll << 31),
-                "conv: tensor exceeds 2^31 elements");
+  DASAC_REQUIRE((int64_t)Nb * Cx * H * W < (1ll << 30) && (int64_t)Nb * M * OutH * OutW < (1ll << 30) &&
+                    (int64_t)Nb * OH * OW < (1ll << 30),
+                "conv: tensor exceeds 2^30 elements (32-bit byte offsets)");
   DASAC_REQUIRE(Kpad % 16 == 0 && Mpad % 32 == 0 && Mpad >= M, "conv: bad padding Kpad=%d Mpad=%d", Kpad, Mpad);
   g.H = H; g.W = W; g.CxHW = Cx * H * W; g.OH = OH; g.OW = OW; g.stride = stride; g.Npix = Nb * OH * OW; g.n_tile0 = 0;
   g.M = M; g.Mpad = Mpad; g.Kpad = Kpad; g.OutH = OutH; g.OutW = OutW; g.ostride = ostride;
-  DASAC_REQUIRE((int64_t)Nb * Cx * H * W * 4 < (1ll << 31) && (int64_t)Nb * M * OH * OW * 4 < (1ll << 31),
-                "conv: tensor exceeds the 2 GiB buffer-descriptor window");
-  DASAC_REQUIRE((int64_t)Nb * M * OutH * OutW * 4 < (1ll << 31), "conv: output exceeds the 2 GiB buffer-descriptor window");
-  g.x_bytes = Nb * Cx * H * W * 4;
-  g.z_bytes = Nb * M * OH * OW * 4;
-  g.out_bytes = Nb * M * OutH * OutW * 4;
+  DASAC_REQUIRE((int64_t)Nb * Cx * H * W * 4 <= kMaxTensorBytes && (int64_t)Nb * M * OH * OW * 4 <= kMaxTensorBytes,
+                "conv: tensor exceeds the 4 GiB buffer-descriptor window");
+  DASAC_REQUIRE((int64_t)Nb * M * OutH * OutW * 4 <= kMaxTensorBytes, "conv: output exceeds the 4 GiB buffer-descriptor window");
+  // (row / plane offsets inside ONE image travel as signed scalar offsets)
+  DASAC_REQUIRE((int64_t)Cx * H * W * 4 < (1ll << 31) && (int64_t)M * OutH * OutW * 4 < (1ll << 31) && (int64_t)M * OH * OW * 4 < (1ll << 31),
+                "conv: one image of a tensor exceeds 2 GiB");
+  g.x_bytes = (unsigned)((int64_t)Nb * Cx * H * W * 4);
+  g.z_bytes = (unsigned)((int64_t)Nb * M * OH * OW * 4);
+  g.out_bytes = (unsigned)((int64_t)Nb * M * OutH * OutW * 4);
   g.w_bytes = 0;
   return DASAC_OK;
 }

@@ -262,7 +262,8 @@ class Engine:
 
     def largest_tensor_bytes(self, Nb, H, W):
         """Bytes of the largest activation (or expanded-conv intermediate) a pass over an [Nb, *, H, W] input creates.  The conv
-        kernels address tensors through 32-bit buffer descriptors: every one of them has to stay below 2 GiB."""
+        kernels address tensors through buffer descriptors with unsigned 32-bit byte offsets: every one of them has to stay below 4 GiB
+        (4 GiB - 4 KiB; rounds 1-4: 2 GiB)."""
         shapes = {0: (None, H, W)}
         biggest = 0
         for op in self.plan.ops:

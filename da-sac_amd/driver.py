@@ -125,7 +125,7 @@ def sac_train_iteration(net, optim, src_batch, tgt_batch, group_size, update_tea
     student -- the same gradient sum, half the launches, one gradient all-reduce per iteration).  Needs the bare module or
     `dasac_hip.parallel.OverlappedDataParallel`; silently runs the two-pass order where it does not apply (target_only, stock
     DistributedDataParallel, batch-statistics BN, crops of different sizes, or a concatenated batch whose largest activation
-    would leave the kernels' 2 GiB addressing window -- FCN-8s at 16 crops of 512x1024)."""
+    would leave the kernels' 4 GiB addressing window (FCN-8s at 16 crops of 512x1024 peaks at exactly 2 GiB: fused since round 5)."""
     core = net.module if hasattr(net, "module") else net
     if fuse_passes and not target_only and hasattr(net, "forward_fused") and hasattr(core, "backbone") and core.backbone._bn_frozen() \
             and tuple(src_batch[0].shape[1:]) == tuple(tgt_batch[0].shape[1:]) \

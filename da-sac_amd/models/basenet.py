@@ -108,10 +108,10 @@ class BaseNet(nn.Module):
         return all(not m.training for m in self.modules() if isinstance(m, BaseNet._batchnorm))
 
     def _batch_fits(self, Nb, H, W):
-        """True when a pass over Nb crops of H x W keeps every activation inside the kernels' 2 GiB addressing window."""
+        """True when a pass over Nb crops of H x W keeps every activation inside the kernels' 4 GiB addressing window."""
         if self._engine is None or self._engine.stale():
             self._engine = E.Engine(self._plan())
-        return self._engine.largest_tensor_bytes(Nb, H, W) < (1 << 31)
+        return self._engine.largest_tensor_bytes(Nb, H, W) <= (1 << 32) - 4096
 
     def _logits(self, im):
         if self._engine is None or self._engine.stale():      # parameter objects replaced -> re-capture the plan

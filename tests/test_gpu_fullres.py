@@ -209,3 +209,47 @@ def test_cfg5_resolution_sample_matches_the_oracle(fuse):
     assert mism < 1e-3
     assert float((net.running_conf.cpu() - ref.running_conf).abs().max()) <= 1e-6
     assert max(worst.values()) <= 1e-4, worst
+
+
+@pytest.mark.gpu
+def test_cfg5_full_batch_fused_student_pass_equals_the_two_passes():
+    """cfg-5 at its FULL per-GPU size (VGG16-FCN8s + SAC, 8 source + 2 x 4 target crops at 512x1024): since round 5 the conv
+    kernels address up to 4 GiB per tensor, so the student's two passes run as ONE 16-crop pass whose first activations are exactly
+    2 GiB (models/fcn.py:136-149, train.py:266-298).  One iteration from the same state through both schedules (Dropout2d p = 0):
+    same losses, same label map, parameters after the SGD step within 1e-4 of their max (run-vs-run across schedules: the
+    weight-gradient reductions sum in another order)."""
+    import copy
+    import torch
+    import torch.nn as nn
+    sys.path.insert(0, ROOT)
+    import bench
+    import driver
+    import models
+    cfg = bench.model_cfg("fcn_vgg16_bn")
+    dev = torch.device("cuda", 0)
+    net = models.get_model(cfg, 0, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    driver.init_synthetic_weights(net, seed=0)
+    net.cuda(0).train()
+    for m in net.modules():
+        if isinstance(m, nn.Dropout2d):
+            m.p = 0.0
+    net.running_conf.fill_(0.05)
+    src, tgt = driver.synthetic_batches(8, 2, 4, (512, 1024), dev, seed=0)
+    driver.calibrate_classifier(net, src[0][:1])
+    src = (src[0], driver.self_consistent_labels(net, src[0]))
+    assert net.backbone._batch_fits(16, 512, 1024), "the fused pass must fit the addressing window"
+    state = copy.deepcopy(net.state_dict())
+    results = {}
+    for fuse in (True, False):
+        net.load_state_dict(state)
+        optim = driver.make_optimizer(net, cfg)
+        tgt_i = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])
+        ls, lt, outs = driver.sac_train_iteration(net, optim, src, tgt_i, 4, update_teacher=True, lr_target=cfg.LR_TARGET, fuse_passes=fuse)
+        torch.cuda.synchronize()
+        results[fuse] = (float(ls["loss_ce"]), float(lt["self_ce"]), outs["teacher_labels"].clone(),
+                         {k: v.detach().clone() for k, v in net.backbone.state_dict().items() if v.dtype.is_floating_point})
+    (la, sa, laba, pa), (lb, sb, labb, pb) = results[True], results[False]
+    assert abs(la - lb) <= 1e-5 * abs(lb) and abs(sa - sb) <= 1e-4 * max(abs(sb), 1e-6), (la, lb, sa, sb)
+    assert torch.equal(laba, labb)                      # the teacher does not depend on the student schedule
+    worst = max(float((pa[k] - pb[k]).abs().max() / pb[k].abs().max().clamp_min(1e-30)) for k in pb)
+    assert worst <= 1e-4, worst
