@@ -226,6 +226,10 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
   // acknowledgement; rounds 1-4 interleaved 8 batches of (loads, 8 stores) and paid 8 store round trips per tile
   // (28-36 us of a 91 us workgroup life on the K = 256 layers, profiles/r3_tile_timeline.txt).
   __shared__ __attribute__((aligned(16))) float s_shift[BM];
+  // byte offset of (image, oh, ow) of each of the tile's BN pixel columns inside one output row, or the poison offset: formed in
+  // the prologue next to the gather's own pixel decode (the same two integer divisions), read back by the epilogue -- whose
+  // instructions are only served where the co-resident K-loop waves stall, ~20 per microsecond (profiles/r5_epilogue_anatomy.txt)
+  __shared__ unsigned s_vo[BN];
   __shared__ __attribute__((aligned(16))) unsigned s_mbits[BITS == 2 ? (BN / 32) * BM : 4];   // [32-pixel group][row]
 
   const int t = threadIdx.x, lane = t & 63;
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
 
     // ---- this thread's pixel column of the gather -------------------------------------------
     int pixbase, ih0, iw0;
+    unsigned pro_vo = kPoison;
     {
       const int pix = n0 + bcol;
       if (pix < g.Npix) {
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
         ih0 = oh * g.stride;
         iw0 = ow * g.stride;
         pixbase = n * g.CxHW + ih0 * g.W + iw0;
+        pro_vo = (unsigned)(n * g.M * OutHW + oh * g.ostride * g.OutW + ow * g.ostride) * 4u;
       } else {
         ih0 = -kInvalid;     // every tap out of bounds -> poison offsets -> zeros
         iw0 = 0;
@@ -396,6 +402,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     DASAC_STORE_TILE(ks & 1);
     if (!STREAMK || ks == 0) {
       if (t < BM) s_shift[t] = pro_shift;
+      if (t < BN) s_vo[t] = pro_vo;
       if constexpr (BITS == 2) {
 #pragma unroll
         for (int u = 0; u < (BN / 32) * BM / kThreads; ++u) s_mbits[t + u * kThreads] = pro_bits[u];
@@ -561,11 +568,13 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
       // row of accumulator register rg of row group i: mrow + (rg&3) + 8*(rg>>2), + 4*lh in the lane offset -> a row exists
       // iff its lane-independent part is below M - 4*lh (one per-lane limit, a compare and a select per access)
       const int mlim = g.M - 4 * lh;
+      const unsigned lane_bit = 1u << li;                      // this lane's pixel inside a mask word
 #define DASAC_ROW(i, rg) (m0 + wm * WM + (i) * 32 + ((rg) & 3) + 8 * ((rg) >> 2))
 #define DASAC_VOFF(i, rg) (FULL ? vo : (DASAC_ROW(i, rg) < mlim ? vo : kPoison))
       // one batch: row groups I0 .. I0+NI-1 of column group j
-      auto batch = [&](int j, unsigned vo, auto i0_tag, auto ni_tag) __attribute__((always_inline)) {
+      auto batch = [&](int j, unsigned vo, auto i0_tag, auto ni_tag, auto relu_tag) __attribute__((always_inline)) {
         constexpr int I0 = decltype(i0_tag)::value, NI = decltype(ni_tag)::value;
+        constexpr bool RELU = decltype(relu_tag)::value;     // compile time: a run-time flag costs a v_max AND a select per element
         const int wcol = (n0 + wn * WN + j * 32) >> 5;          // this wave's 32-pixel group = one word column of the bit masks
         float rs[NI][16], mk[NI][16];
         if (ep.res) {
@@ -596,9 +605,9 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
               const int rg = 4 * q + e;
               float v = acc[i][j][rg] + sh4[e];
               if (ep.res) v = v + rs[i - I0][rg];
-              if (ep.relu) v = fmaxf(v, 0.f);
+              if constexpr (RELU) v = fmaxf(v, 0.f);
               if (BITS != 2 && ep.mask) v = mk[i - I0][rg] > 0.f ? v : 0.f;
-              if constexpr (BITS == 2) v = ((mb4[e] >> li) & 1u) ? v : 0.f;
+              if constexpr (BITS == 2) v = (mb4[e] & lane_bit) ? v : 0.f;
 #ifndef DASAC_EXP_NOSTORE
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, DASAC_VOFF(i, rg), DASAC_ROW(i, rg) * OutHWe * 4, 0);
 #else
@@ -617,21 +626,20 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
       };
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int pix = n0 + wn * WN + j * 32 + li;
-        unsigned vo = kPoison;
-        if (pix < g.Npix) {
-          const int n = pix / OHW, r = pix - n * OHW;
-          const int oh = r / g.OW, ow = r - oh * g.OW;
-          vo = (unsigned)(n * g.M * OutHWe + oh * g.ostride * g.OutW + ow * g.ostride + 4 * lh * OutHWe) * 4u;
-        }
+        unsigned vo = s_vo[wn * WN + j * 32 + li];
+        vo = vo == kPoison ? kPoison : vo + (unsigned)(4 * lh * OutHWe) * 4u;      // + the lane half's four rows
         using c0 = std::integral_constant<int, 0>;
         using c1 = std::integral_constant<int, 1>;
-        if (TM == 2 && BITS != 2 && ep.res && ep.mask) {   // residual AND fp32 mask: 2 x 16 loaded values per row group -> one group per batch
-          batch(j, vo, c0{}, c1{});
-          if constexpr (TM == 2) batch(j, vo, c1{}, c1{});
-        } else {
-          batch(j, vo, c0{}, std::integral_constant<int, TM>{});
-        }
+        auto run = [&](auto relu_tag) __attribute__((always_inline)) {
+          if (TM == 2 && BITS != 2 && ep.res && ep.mask) {   // residual AND fp32 mask: 2 x 16 loaded values per row group -> one group per batch
+            batch(j, vo, c0{}, c1{}, relu_tag);
+            if constexpr (TM == 2) batch(j, vo, c1{}, c1{}, relu_tag);
+          } else {
+            batch(j, vo, c0{}, std::integral_constant<int, TM>{}, relu_tag);
+          }
+        };
+        if (ep.relu) run(std::true_type{});
+        else run(std::false_type{});
       }
 #undef DASAC_ROW
 #undef DASAC_VOFF
