@@ -735,13 +735,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_partials(const float* __rest
                                                              float* __restrict__ dz, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
   const int plane = blockIdx.y, c = plane % C, n = plane / C;
+  // the channel's N * chunks partial pairs: strided over the block (independent loads) and folded by a fixed tree -- the same
+  // order in every block and every run; round 4 had every thread walk all of them serially (75-300 dependent loads per block)
+  __shared__ double red_s[256], red_q[256];
   double s = 0, q = 0;
-  for (int j = 0; j < N * chunks_r; ++j) {
+  for (int j = threadIdx.x; j < N * chunks_r; j += 256) {
     const int nn = j / chunks_r, k = j - nn * chunks_r;
     const double* o = partial + ((size_t)(nn * C + c) * chunks_r + k) * 2;
     s += o[0];
     q += o[1];
   }
+  red_s[threadIdx.x] = s;
+  red_q[threadIdx.x] = q;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red_s[threadIdx.x] += red_s[threadIdx.x + o];
+      red_q[threadIdx.x] += red_q[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  s = red_s[0];
+  q = red_q[0];
   if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;

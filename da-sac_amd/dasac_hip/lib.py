@@ -134,6 +134,8 @@ def check_device(index):
     waves, 256 CUs in 8 XCDs).  A partitioned (CPX / fewer-CU) device would run with mistuned grids and a refused stream-K
     schedule; DASAC_ALLOW_OTHER_DEVICE=1 turns the error into a warning for experiments."""
     if index in _checked_devices:
+        if isinstance(_checked_devices[index], DasacError):
+            raise _checked_devices[index]
         return _checked_devices[index]
     lib = load()
     cus, wave, arch = _i(0), _i(0), C.create_string_buffer(64)
@@ -156,8 +158,15 @@ def require_gpu(*tensors):
         if t is not None:
             if not t.is_cuda:
                 raise DasacError("dasac_hip ops run on the MI355X only (got a {} tensor); no CPU fallback".format(t.device))
-            if t.device.index not in _checked_devices:
-                check_device(t.device.index)
+            known = _checked_devices.get(t.device.index)
+            if known is None:
+                try:
+                    check_device(t.device.index)
+                except DasacError as exc:          # remember the refusal too: one dasac_device_info call per device, not per op
+                    _checked_devices[t.device.index] = exc
+                    raise
+            elif isinstance(known, DasacError):
+                raise known
 
 
 _ws_cache = {}

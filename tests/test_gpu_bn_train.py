@@ -182,3 +182,34 @@ def test_syncbn_two_ranks_match_one_process_on_the_concatenated_batch():
             assert rel_err(got[r][2][k], ref.student[k].detach()) < 1e-3, (r, k)
     for k in _SYNC_PROBE:
         assert (got[0][2][k] == got[1][2][k]).all(), k
+
+
+@pytest.mark.gpu
+def test_tile_statistics_on_an_ill_conditioned_channel_stay_within_the_documented_bound():
+    """since round 4 the batch statistics come from fp32 per-tile sums / sums of squares (only the cross-tile add is in
+    double) and var = E[x^2] - mean^2.  For a channel whose |mean| is ~100 x its std (a raw conv + bias output) the 1e-7 relative
+    error of an fp32 sum of squares is amplified by mean^2 / var = 1e4: documented bound 2e-3 on var (1e-3 on invstd), against
+    the 1e-6 the well-conditioned channels of the other tests hold.  The stand-alone statistics pass (double accumulation of every
+    element) stays at 1e-6 and is what SyncBN across ranks uses."""
+    import torch.nn as nn
+    from dasac_hip import ops
+    g = torch.Generator().manual_seed(4)
+    N, C, H, W = 2, 256, 65, 65
+    spec = ops.ConvSpec(64, C, [(1, 1, 1, 0)], 1)
+    x = torch.randn(N, 64, H, W, generator=g).cuda()
+    w = (torch.randn(C, 64, 1, 1, generator=g) / 8.0).cuda()
+    bias = torch.full((C,), 100.0).cuda()                      # mean = 100 x std
+    order = ops.gemm_order(spec, False)
+    table, packed = ops.conv_table(spec, H, W, False, x.device, order), ops.conv_pack(spec, [w], False, None, order=order)
+    z = torch.empty(N, C, H, W, device="cuda")
+    ts = ops.tile_stats_buffer(N, C, H, W, x.device)
+    ops.conv_gemm(x, packed, table, z, (H, W), 1, C, spec.K, 1, bias, stats=ts)
+    bn_t, bn_p = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
+    _, (mean_t, inv_t, _, _) = ops.bn_train_forward(z, bn_t, None, False, tile_stats=ts)
+    _, (mean_p, inv_p, _, _) = ops.bn_train_forward(z, bn_p, None, False)
+    zd = z.double()
+    mean_ref = zd.mean((0, 2, 3))
+    inv_ref = (zd.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
+    assert float(((mean_t.double() - mean_ref) / mean_ref).abs().max()) < 1e-6
+    assert float(((inv_p.double() - inv_ref) / inv_ref).abs().max()) < 1e-5           # stand-alone pass: double accumulation
+    assert float(((inv_t.double() - inv_ref) / inv_ref).abs().max()) < 1e-3           # tile sums: the documented bound

@@ -156,7 +156,8 @@ def test_small_batch_stream_k_with_several_contributors(case):
     """Inference / cfg-2 sized launches: the persistent schedule cuts a tile into more than two ranges; the worker
     holding its first K-steps sums the deposits of all the following ones."""
     from dasac_hip import ops
-    name, cin, cout, br, (N, H, W) = case
+    name, cin, cout, br, (N, H, W) = case[:5]
+    sched = case[5] if len(case) > 5 else None
     spec = ops.ConvSpec(cin, cout, [br], 1)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(N, cin, H, W, generator=g)
@@ -289,6 +290,9 @@ STATS_CASES = [
     ("tiles_1x1", 64, 256, (1, 1, 1, 0), (2, 25, 33)),
     ("streamk_3x3", 128, 256, (3, 3, 2, 2), (2, 33, 41)),
     ("ragged_m200", 128, 200, (3, 3, 2, 2), (3, 9, 13)),
+    # forced stream-K with MORE tiles than workers (1178 tiles x 4 K-steps over 768 workers: a worker finishes one tile's epilogue and
+    # starts the next tile): the statistics scratch aliases the operand LDS of the next tile -- the loop-end barrier orders them
+    ("streamk_consecutive_tiles", 64, 256, (1, 1, 1, 0), (8, 97, 97), 2),
 ]
 
 
@@ -300,7 +304,8 @@ def test_gemm_epilogue_channel_statistics(case):
     stand-alone statistics pass."""
     import torch.nn as nn
     from dasac_hip import ops
-    name, cin, cout, br, (N, H, W) = case
+    name, cin, cout, br, (N, H, W) = case[:5]
+    sched = case[5] if len(case) > 5 else None
     spec = ops.ConvSpec(cin, cout, [br], 1)
     g = torch.Generator().manual_seed(7)
     x = (torch.randn(N, cin, H, W, generator=g) + 0.3).cuda()
@@ -311,12 +316,12 @@ def test_gemm_epilogue_channel_statistics(case):
     table, packed = ops.conv_table(spec, H, W, False, x.device, order), ops.conv_pack(spec, [w], False, None, order=order)
     OH, OW = spec.out_hw(H, W)
     plain = torch.empty((N, cout, OH, OW), device="cuda")
-    ops.conv_gemm(x, packed, table, plain, (OH, OW), 1, cout, spec.K, 1, bias)
+    ops.conv_gemm(x, packed, table, plain, (OH, OW), 1, cout, spec.K, 1, bias, schedule=sched)
     runs = []
     for _ in range(2):
         out = torch.empty_like(plain)
         ts = ops.tile_stats_buffer(N, cout, OH, OW, x.device).fill_(float("nan"))
-        ops.conv_gemm(x, packed, table, out, (OH, OW), 1, cout, spec.K, 1, bias, stats=ts)
+        ops.conv_gemm(x, packed, table, out, (OH, OW), 1, cout, spec.K, 1, bias, stats=ts, schedule=sched)
         runs.append((out, ts))
     (out, ts), (out2, ts2) = runs
     assert torch.equal(out, plain) and torch.equal(out2, plain) and torch.equal(ts, ts2)
