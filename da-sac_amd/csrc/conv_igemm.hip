@@ -544,14 +544,10 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
     const bool deposited = STREAMK && ks > 0;                // this worker only contributed a partial sum
     DASAC_STAMP(2);
-#ifndef DASAC_EXP_NOPRIO
-    // VALU issue on a SIMD is arbitrated by priority, then age, and an MFMA waiting for the matrix pipe holds the slot: next to
-    // three waves in their K loops an epilogue wave gets about one vector-ALU instruction per 64-cycle MFMA (measured in round 5:
-    // 21-26 us from the end of the K loop to the last store ISSUED -- with the stores compiled out just the same -- and 2 us for their
-    // acknowledgements).  At priority 3 the epilogue's few hundred VALU instructions issue back to back and the workgroup returns
-    // its slot ~20 us earlier; the matrix pipe loses the same issue slots either way.
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    // (Round 5, measured: __builtin_amdgcn_s_setprio(3) for the epilogue changes nothing -- 21.0 vs 21.3 us from the end of the K loop to
+    // the last store issued, profiles/r5_epilogue_anatomy.txt: a wave with an MFMA ready is served first whatever the priorities are.
+    // An s_nop 15 after every (second, fourth) MFMA of the short-K launches, to open issue windows for co-resident prologue /
+    // epilogue waves, buys 1-2.5 % on the K = 256 layers and costs 0.7 % at K = 4608: not kept.)
     if (!deposited) {
     if constexpr (BITS != 3) {
     // Per 32-pixel column group j: ONE batch of loads (the residual and / or an fp32 mask, TM x 16 values; shift and mask words
@@ -728,9 +724,6 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
       }
     }
     }
-#ifndef DASAC_EXP_NOPRIO
-    if (STREAMK) __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef DASAC_TRACE_TILES
     DASAC_STAMP(5);                                    // the epilogue's stores have been issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and acknowledged

@@ -20,7 +20,8 @@ for spec in sys.argv[1:]:
         objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs if not s.endswith("conv_igemm.hip")] + [o]
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
         env["DASAC_LIB"] = out
-    for shape, m in shapes:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "one_conv.py"), shape, m, "20", "16"], env=env, capture_output=True, text=True)
+    for sh in shapes:
+        shape, m, B = sh[0], sh[1], (sh[2] if len(sh) > 2 else "16")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "one_conv.py"), shape, m, "20", B], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("done")]
         print("{:14s} {}".format(name, line[0][5:].split("checksum")[0] if line else "FAILED " + r.stderr[-300:]), flush=True)
