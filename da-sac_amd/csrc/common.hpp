@@ -50,6 +50,22 @@ inline int stream_grid(int64_t work_items, int block, int max_blocks = 0) {
   return static_cast<int>(g);
 }
 
+// ---- n / d for 0 <= n < 2^31 and a launch-constant d >= 1: one v_mul_hi_u32 + one shift instead of the ~30-instruction
+// runtime division (the streaming kernels are issue-bound on exactly such index math: tools/isa_count.py).
+// l = ceil(log2 d), mul = ceil(2^(31+l) / d) < 2^32, n / d = (n * mul) >> (31 + l)  (exact: 2^(31+l) <= mul*d <= 2^(31+l) + 2^l);
+// d = 1 is flagged by mul = 0.
+struct FastDiv {
+  unsigned mul, shift;
+};
+inline FastDiv fast_div(int d) {
+  if (d <= 1) return FastDiv{0u, 0u};
+  int l = 1;
+  while ((1ll << l) < d) ++l;
+  const unsigned long long p = 1ull << (31 + l);
+  return FastDiv{(unsigned)((p + (unsigned)d - 1) / (unsigned)d), (unsigned)(l - 1)};
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) { return f.mul ? (int)(__umulhi((unsigned)n, f.mul) >> f.shift) : n; }
+
 // ---- wave / block reductions (64-wide) ------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -12,6 +12,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <atomic>
 
@@ -39,6 +40,14 @@ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
   return t;
 }
 
+// scalar base + 32-bit per-lane byte offset: the form the global_load / global_store saddr encoding takes without any VALU
+__device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float* at_off(float* base, unsigned byte_off) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off);
+}
+
 // Four consecutive high-res pixels of one row per thread, loop over classes.  Optional outputs:
 //   up    [B,C,H,W]  upsampled logits
 //   probs [B,C,H,W]  softmax(up) * (ignore ? 0 : 1)
@@ -50,13 +59,14 @@ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
 // three low-res columns, so a class costs 6 L1/L2 loads per 4 pixels instead of 16.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-template <int CT, bool SOFTMAX>
+template <int CT, bool SOFTMAX, bool NARROW>
 __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict__ x, int Crt, int h, int w, int H, int W,
                                                         float sh, float sw, const uint8_t* __restrict__ ignore,
                                                         float* __restrict__ up, float* __restrict__ probs,
-                                                        unsigned long long* __restrict__ csum, int64_t items) {
+                                                        unsigned long long* __restrict__ csum, int items, FastDiv div_wq) {
   const int C = CT < kMaxC ? CT : Crt;          // CT == kMaxC is the generic (runtime-C) instantiation
   const int HW = H * W, hw = h * w, Wq = (W + 3) >> 2;
+  const int b = blockIdx.y;                     // one image per block row: every plane base below is a scalar
   __shared__ unsigned long long s_sum[kMaxC];
   if (csum) {
     if (threadIdx.x < kMaxC) s_sum[threadIdx.x] = 0ull;
@@ -65,10 +75,11 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
   float acc[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) acc[c] = 0.f;
-  for (int64_t it = (int64_t)blockIdx.x * kHB + threadIdx.x; it < items; it += (int64_t)gridDim.x * kHB) {
-    const int q = (int)(it % Wq);
-    const int64_t row = it / Wq;                 // b*H + y
-    const int oy = (int)(row % H), b = (int)(row / H);
+  // Round 5 (the kernel is issue-bound: ~4000 VALU instructions per 4 pixels in the probs path, tools/isa_count.py): the image
+  // is the block row, so the class planes are scalar bases + ONE 32-bit per-lane byte offset shared by all classes (no 64-bit
+  // per-lane address arithmetic per load / store); row / quad index by FastDiv; one select per tap instead of two.
+  for (int it = blockIdx.x * kHB + threadIdx.x; it < items; it += gridDim.x * kHB) {
+    const int oy = fdiv(it, div_wq), q = it - oy * Wq;
     const int ox = q * 4, nx = min(4, W - ox);
     const float* xb = x + (size_t)b * C * hw;
     const Tap ty = tap_ac(oy, sh, h);
@@ -76,25 +87,34 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) tx[e] = tap_ac(min(ox + e, W - 1), sw, w);
     const int c_lo = tx[0].i0;
-    const bool narrow = tx[3].i1 - c_lo <= 2;               // the usual case: <= 3 low-res columns under the 4 pixels
+    // the usual case: the 4 pixels start in low-res column c_lo or c_lo + 1, so their taps are (t0,t1) or (t1,t2) -- t1, t2 read
+    // at clamped columns, which is exactly where tap_ac puts i1 on the last column
+    // (NARROW: the launcher has checked every quad of a row -- the up-factor-8 case; the kernel then carries no second path:
+    // 131 instead of 207 VGPRs in the probs instantiation, three waves per SIMD instead of two)
+    const bool narrow = NARROW || tx[3].i0 - c_lo <= 1;
     const int r0 = ty.i0 * w, r1 = ty.i1 * w;
     const int k1 = min(c_lo + 1, w - 1), k2 = min(c_lo + 2, w - 1);
+    const unsigned a00 = (unsigned)(r0 + c_lo) * 4u, a01 = (unsigned)(r0 + k1) * 4u, a02 = (unsigned)(r0 + k2) * 4u;
+    const unsigned a10 = (unsigned)(r1 + c_lo) * 4u, a11 = (unsigned)(r1 + k1) * 4u, a12 = (unsigned)(r1 + k2) * 4u;
+    bool hi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hi[e] = tx[e].i0 != c_lo;
     float v[4][SOFTMAX ? CT : 1];                 // SOFTMAX: all classes of the 4 pixels stay in registers
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    const size_t obase = (size_t)b * C * HW + (size_t)oy * W + ox;
+    const size_t obase = (size_t)b * C * HW;      // scalar
+    const unsigned ooff = (unsigned)(oy * W + ox) * 4u;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       if (c < C) {
         const float* pl = xb + (size_t)c * hw;
         float val[4];
         if (narrow) {
-          const float t0 = pl[r0 + c_lo], t1 = pl[r0 + k1], t2 = pl[r0 + k2];
-          const float b0 = pl[r1 + c_lo], b1 = pl[r1 + k1], b2 = pl[r1 + k2];
+          const float t0 = ld_off(pl, a00), t1 = ld_off(pl, a01), t2 = ld_off(pl, a02);
+          const float b0 = ld_off(pl, a10), b1 = ld_off(pl, a11), b2 = ld_off(pl, a12);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int d0 = tx[e].i0 - c_lo, d1 = tx[e].i1 - c_lo;
-            const float ta = d0 == 0 ? t0 : (d0 == 1 ? t1 : t2), tb = d1 == 0 ? t0 : (d1 == 1 ? t1 : t2);
-            const float ba = d0 == 0 ? b0 : (d0 == 1 ? b1 : b2), bb = d1 == 0 ? b0 : (d1 == 1 ? b1 : b2);
+            const float ta = hi[e] ? t1 : t0, tb = hi[e] ? t2 : t1;
+            const float ba = hi[e] ? b1 : b0, bb = hi[e] ? b2 : b1;
             const float top = tx[e].w0 * ta + tx[e].w1 * tb;
             const float bot = tx[e].w0 * ba + tx[e].w1 * bb;
             val[e] = ty.w0 * top + ty.w1 * bot;
@@ -114,7 +134,7 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
             mx[e] = fmaxf(mx[e], val[e]);
           }
         } else {                                     // logits only: stream the class plane out, nothing kept
-          float* o = up + obase + (size_t)c * HW;
+          float* o = at_off(up + obase + (size_t)c * HW, ooff);
           if (nx == 4) {
             *reinterpret_cast<f32x4u*>(o) = f32x4u{val[0], val[1], val[2], val[3]};
           } else {
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
 #pragma unroll
       for (int c = 0; c < CT; ++c)
         if (c < C) {
-          float* o = up + obase + (size_t)c * HW;
+          float* o = at_off(up + obase + (size_t)c * HW, ooff);
           if (nx == 4) {
             *reinterpret_cast<f32x4u*>(o) = f32x4u{v[0][c], v[1][c], v[2][c], v[3][c]};
           } else {
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
             den += v[e][c];
           }
         inv[e] = 1.f / den;
-        ign[e] = ignore && e < nx && ignore[(size_t)b * HW + (size_t)oy * W + ox + e];
+        ign[e] = ignore && e < nx && ignore[(size_t)b * HW + (size_t)(oy * W + ox + e)];
       }
 #pragma unroll
       for (int c = 0; c < CT; ++c)
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
             if (ign[e]) pr[e] = 0.f;
           }
           if (probs) {
-            float* o = probs + obase + (size_t)c * HW;
+            float* o = at_off(probs + obase + (size_t)c * HW, ooff);
             if (nx == 4) {
               *reinterpret_cast<f32x4u*>(o) = f32x4u{pr[0], pr[1], pr[2], pr[3]};
             } else {
@@ -608,6 +628,141 @@ __global__ __launch_bounds__(kCB) void ce_bwd_rows(const float* __restrict__ xup
   }
 }
 
+// Round 5: the same two phases with ONE WAVE per block walking `rows` consecutive high-res rows of its segment.
+// What the kernel above spends its time on (tools/isa_count.py, the PMC table): every block loads, waits, computes, synchronises
+// and reduces exactly once -- the 19 plane loads of a row are never in flight while anything else happens, each row rebuilds the
+// (row-independent) tap weights of its columns (as many instructions as the reduction itself), and 75 of its 128 threads have a
+// quad in phase 1.  Here
+//   * the x range of a segment is at most 256 pixels = one quad per lane, and the NEXT row's planes, labels and confidence sums
+//     are requested right after this row's softmax has left the registers: they land during phase 2;
+//   * a thread keeps its column's SPAN tap weights and LDS indices in registers for all rows;
+//   * a one-wave block needs no cross-wave barrier, and seven of them fit a CU (22 KB of LDS each).
+// Per pixel and per column the arithmetic and its order are those of ce_bwd_rows: identical bits.
+constexpr int kCW = 64;
+typedef long long i64x2u __attribute__((ext_vector_type(2), aligned(8)));
+template <int CT, int SPAN>
+__global__ __launch_bounds__(kCW, 2) void ce_bwd_rows_wave(const float* __restrict__ xup, const int64_t* __restrict__ y,
+                                                       const float* __restrict__ cw, int B, int H, int W, int w, float sw, int mode,
+                                                       const float* __restrict__ gscale, float* __restrict__ tmp, int seg_cols,
+                                                       int n_seg, int pitch, const float* __restrict__ cs_pix, int rows, int n_chunks) {
+  extern __shared__ float s_d[];                      // [CT][pitch]
+  const int seg = blockIdx.x % n_seg, rest = blockIdx.x / n_seg;
+  const int rc = rest % n_chunks, b = rest / n_chunks;
+  const int y0 = rc * rows, y1 = min(H, y0 + rows);
+  const int j0 = seg * seg_cols, j1 = min(w, j0 + seg_cols);
+  int xs, xe, dummy;
+  src_range(j0, sw, W, xs, dummy);
+  src_range(j1 - 1, sw, W, dummy, xe);
+  xs &= ~3;
+  const int HW = H * W;
+  const float gs = gscale ? gscale[0] : 1.f;
+  const float norm = mode == 1 ? 1.f / ((float)B * (float)B * (float)HW) : 1.f / ((float)B * (float)HW);
+  // phase-1 role: the quad at xs + 4 * lane (the launcher guarantees xe - xs < 256 and W >= 4).  A quad that hangs over the end
+  // of the row is LOADED four pixels back from the row's end and rotated into place (one lane of one segment per row): every
+  // load is a full dwordx4, and a quad's four LDS slots are consecutive (xs and the quads are multiples of 4, the index skew
+  // steps every 8), so the 76 LDS writes take 19 base registers + immediate offsets.
+  const int ox = xs + (int)threadIdx.x * 4;
+  const bool act = ox <= xe;
+  const int rot = max(0, ox + 4 - W), ox_ld = ox - rot;
+  // phase-2 role: column j, classes g0, g0 + groups, ...
+  const int nj = j1 - j0;
+  const int groups = max(1, min(CT, kCW / nj));
+  const bool red = (int)threadIdx.x < nj * groups;
+  const int j = j0 + (int)threadIdx.x % nj, g0 = (int)threadIdx.x / nj;
+  int lo, hi;
+  src_range(j, sw, W, lo, hi);
+  const int n = hi - lo + 1;                              // <= SPAN (launcher)
+  float wt[SPAN];
+  int li[SPAN];
+#pragma unroll
+  for (int i = 0; i < SPAN; ++i) {
+    wt[i] = i < n ? weight_to(lo + i, sw, w, j) : 0.f;
+    li[i] = ce_lds_index(min(lo + i, hi) - xs);
+  }
+  __shared__ float s_cw[CT];                              // class weights: an LDS lookup by label, not a dependent global load
+  if (threadIdx.x < CT) s_cw[threadIdx.x] = cw ? cw[threadIdx.x] : 1.f;
+  __syncthreads();
+  f32x4u v[CT];
+  f32x4u cs;
+  int64_t lab[4];
+  auto load_row = [&](int oy) {
+    if (!act) return;
+    const int p = oy * W + ox_ld;
+    const float* base = xup + (size_t)b * CT * HW + p;
+    const int64_t* yp = y + (size_t)b * HW + p;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) v[c] = *reinterpret_cast<const f32x4u*>(base + (size_t)c * HW);
+    const i64x2u l01 = *reinterpret_cast<const i64x2u*>(yp), l23 = *reinterpret_cast<const i64x2u*>(yp + 2);
+    lab[0] = l01[0]; lab[1] = l01[1]; lab[2] = l23[0]; lab[3] = l23[1];
+    cs = mode == 1 ? *reinterpret_cast<const f32x4u*>(cs_pix + p) : f32x4u{1.f, 1.f, 1.f, 1.f};
+  };
+  load_row(y0);
+  for (int oy = y0; oy < y1; ++oy) {
+    if (act) {
+      if (rot) {                                          // element e <- element e + rot (what lands beyond the row is never read)
+        auto turn = [&](auto& q) {
+          q[0] = rot == 1 ? q[1] : (rot == 2 ? q[2] : q[3]);
+          q[1] = rot == 1 ? q[2] : q[3];
+          q[2] = q[3];
+        };
+#pragma unroll
+        for (int c = 0; c < CT; ++c) turn(v[c]);
+        turn(cs);
+      }
+      int lb[4];                                          // label, or -1 (ignored / out of range: matches no class)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lb[e] = (lab[e] >= 0 && lab[e] < CT) ? (int)lab[e] : -1;
+      if (rot) {
+        lb[0] = rot == 1 ? lb[1] : (rot == 2 ? lb[2] : lb[3]);
+        lb[1] = rot == 1 ? lb[2] : lb[3];
+        lb[2] = lb[3];
+      }
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], v[c][e]);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[c][e] = expf(v[c][e] - mx[e]);
+          den[e] += v[c][e];
+        }
+      float k[4], gw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float wgt = lb[e] >= 0 ? s_cw[max(lb[e], 0)] : 0.f;
+        const float gpw = cs[e] * norm * gs;
+        gw[e] = gpw * wgt;
+        k[e] = gw[e] / den[e];
+      }
+      float* wr = s_d + ce_lds_index(ox - xs);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wr[c * pitch + e] = k[e] * v[c][e] - ((c == lb[e]) ? gw[e] : 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);                    // not earlier: the next row reuses this row's 76 registers
+    if (oy + 1 < y1) load_row(oy + 1);                    // in flight while this row is reduced
+    __syncthreads();
+    if (red) {
+#pragma unroll 1
+      for (int c = g0; c < CT; c += groups) {
+        const float* row = s_d + c * pitch;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < SPAN; ++i) {
+          const float t = acc + wt[i] * row[li[i]];
+          acc = i < n ? t : acc;                            // a select, not a branch per tap
+        }
+        tmp[((size_t)(b * CT + c) * H + oy) * w + j] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- affine warps: affine_grid + grid_sample(bilinear, zeros, align_corners=False) -------------
 struct Sample {
   int o00, o01, o10, o11;     // flat offsets (clamped)
@@ -799,17 +954,65 @@ __global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ p
 // refined[b] = sample(pooled[g(b)], theta_inv[b]) * sample(mask[g(b)], theta_inv[b]),  g(b) = group_of[b]
 // (round 4, measured: a compile-time class count with all 4 x 19 taps of a pixel in flight makes this kernel SLOWER -- 327 vs
 // 213 us at 8 x 19 x 769^2: the registers of 76 gathers in flight cost more occupancy than the batching wins; the class loop stays)
+// Round 5: a thread owns the pixel (2r, x) AND the one below it.  The counters showed 2.4x the algorithmic bytes entering L2: the
+// row below re-reads the lower source row of the row above, and in the linear pixel order that neighbour is another block on
+// another XCD (its own L2).  With both rows in one thread the shared source row is fetched once per row PAIR, and a class has
+// eight independent taps in flight instead of four (the loop was latency-bound: 22 VALU instructions per class, 4 gathers).
+// The block still walks the pair-of-rows plane linearly, so the 2 x 19 store streams stay sequential in DRAM; per pixel the same
+// make_sample / take arithmetic: identical bits.  Class planes are scalar bases + 32-bit per-lane byte offsets.
+__device__ __forceinline__ float take_off(const float* __restrict__ pl, const Sample& s) {
+  return ld_off(pl, (unsigned)s.o00 * 4u) * s.w00 + ld_off(pl, (unsigned)s.o01 * 4u) * s.w01 + ld_off(pl, (unsigned)s.o10 * 4u) * s.w10 +
+         ld_off(pl, (unsigned)s.o11 * 4u) * s.w11;
+}
 __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ pooled, const float* __restrict__ mask,
                                                  const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
-                                                 float* __restrict__ refined, int blocks_per_image) {
+                                                 float* __restrict__ refined, int blocks_per_image, int items, FastDiv div_w) {
   const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
   const int n = b / group_div;
   const int HW = H * W;
-  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
-    const Sample s = make_sample(theta_inv + b * 6, p / W, p % W, H, W);
-    const float mv = take(mask + (size_t)n * HW, s);
-    for (int c = 0; c < C; ++c)
-      refined[((size_t)b * C + c) * HW + p] = take(pooled + ((size_t)n * C + c) * HW, s) * mv;
+  for (int it = chunk * kHB + threadIdx.x; it < items; it += blocks_per_image * kHB) {
+    const int r = fdiv(it, div_w), ox = it - r * W;
+    const int oy = 2 * r;
+    const Sample s0 = make_sample(theta_inv + b * 6, oy, ox, H, W);
+    const float* mp = mask + (size_t)n * HW;
+    const float mv0 = take_off(mp, s0);
+    const unsigned o0 = (unsigned)(oy * W + ox) * 4u, o1 = o0 + (unsigned)W * 4u;
+    // classes two at a time, all their taps issued before the first is used.  `two` (a second row exists: everywhere but on the
+    // last row of an odd H) is a compile-time tag -- as a run-time predicate the compiler sinks the second row's taps under it
+    // and waits for four loads at a time.
+    auto rows = [&](auto two_tag) {
+      constexpr bool TWO = decltype(two_tag)::value;
+      const Sample s1 = TWO ? make_sample(theta_inv + b * 6, oy + 1, ox, H, W) : s0;
+      const float mv1 = TWO ? take_off(mp, s1) : 0.f;
+      auto batch = [&](int c, auto nc_tag) {
+        constexpr int NC = decltype(nc_tag)::value;
+        float t0[NC][4], t1[NC][4];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+          const float* pl = pooled + ((size_t)n * C + c + u) * HW;
+          t0[u][0] = ld_off(pl, (unsigned)s0.o00 * 4u); t0[u][1] = ld_off(pl, (unsigned)s0.o01 * 4u);
+          t0[u][2] = ld_off(pl, (unsigned)s0.o10 * 4u); t0[u][3] = ld_off(pl, (unsigned)s0.o11 * 4u);
+          if (TWO) {
+            t1[u][0] = ld_off(pl, (unsigned)s1.o00 * 4u); t1[u][1] = ld_off(pl, (unsigned)s1.o01 * 4u);
+            t1[u][2] = ld_off(pl, (unsigned)s1.o10 * 4u); t1[u][3] = ld_off(pl, (unsigned)s1.o11 * 4u);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+          float* out = refined + ((size_t)b * C + c + u) * HW;
+          const float a0 = t0[u][0] * s0.w00 + t0[u][1] * s0.w01 + t0[u][2] * s0.w10 + t0[u][3] * s0.w11;
+          *at_off(out, o0) = a0 * mv0;
+          if (TWO) {
+            const float a1 = t1[u][0] * s1.w00 + t1[u][1] * s1.w01 + t1[u][2] * s1.w10 + t1[u][3] * s1.w11;
+            *at_off(out, o1) = a1 * mv1;
+          }
+        }
+      };
+      int c = 0;
+      for (; c + 2 <= C; c += 2) batch(c, std::integral_constant<int, 2>{});
+      if (c < C) batch(c, std::integral_constant<int, 1>{});
+    };
+    if (oy + 1 < H) rows(std::true_type{}); else rows(std::false_type{});
   }
 }
 
@@ -855,17 +1058,27 @@ extern "C" int dasac_upsample_softmax(const float* logits, int B, int C, int h, 
   DASAC_REQUIRE(B > 0 && C > 0 && C <= kMaxC && h > 0 && w > 0 && H > 0 && W > 0, "upsample_softmax: bad shape");
   hipStream_t s = as_stream(stream);
   if (class_sums) DASAC_HIP(hipMemsetAsync(class_sums, 0, C * sizeof(double), s));
-  const int64_t items = (int64_t)B * H * ((W + 3) / 4);
+  DASAC_REQUIRE(B < 65536 && (int64_t)H * W < (1ll << 30) && (int64_t)h * w < (1ll << 30), "upsample_softmax: plane too large");
+  const int Wq = (W + 3) / 4, items = H * Wq;    // per image: grid.y is the image
   const bool softmax = probs || class_sums;
   // softmax path: a few items per thread so that the class-sum reduction at the end is amortised
-  const int grid = stream_grid(items, kHB, softmax ? kNumCu * 4 : kNumCu * 16);
-#define DASAC_UPS(CT, SM)                                                                                              \
-  hipLaunchKernelGGL((upsample_softmax<CT, SM>), dim3(grid), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), \
-                     ac_scale(w, W), ignore, up, probs, reinterpret_cast<unsigned long long*>(class_sums), items)
-  if (C == 19) {
-    if (softmax) DASAC_UPS(19, true); else DASAC_UPS(19, false);
+  const int total = stream_grid((int64_t)B * items, kHB, softmax ? kNumCu * 4 : kNumCu * 16);
+  const int grid = std::max(1, std::min((items + kHB - 1) / kHB, (total + B - 1) / B));
+  const float sw = ac_scale(w, W);
+  bool narrow = true;                            // tap_ac's column arithmetic, on the host (one fp32 multiply: same bits)
+  for (int ox = 0; ox < W && narrow; ox += 4) {
+    auto col = [&](int dst) { return std::min((int)(sw * (float)dst), w - 1); };
+    narrow = col(std::min(ox + 3, W - 1)) - col(ox) <= 1;
+  }
+#define DASAC_UPS(CT, SM, NW)                                                                                                  \
+  hipLaunchKernelGGL((upsample_softmax<CT, SM, NW>), dim3(grid, B), dim3(kHB), 0, s, logits, C, h, w, H, W, ac_scale(h, H), \
+                     sw, ignore, up, probs, reinterpret_cast<unsigned long long*>(class_sums), items, fast_div(Wq))
+  if (C == 19 && narrow) {
+    if (softmax) DASAC_UPS(19, true, true); else DASAC_UPS(19, false, true);
+  } else if (C == 19) {
+    if (softmax) DASAC_UPS(19, true, false); else DASAC_UPS(19, false, false);
   } else {
-    if (softmax) DASAC_UPS(kMaxC, true); else DASAC_UPS(kMaxC, false);
+    if (softmax) DASAC_UPS(kMaxC, true, false); else DASAC_UPS(kMaxC, false, false);
   }
 #undef DASAC_UPS
   DASAC_CHECK_LAUNCH("upsample_softmax");
@@ -995,7 +1208,48 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
     DASAC_CHECK_LAUNCH("conf_pixel_sums");
     cs_pix = cs;
   }
-  if (C == 19)
+  // the one-wave kernel: 19 classes, segments of at most 256 pixels, at most 24 taps per column, confidence sums precomputed
+  bool wave_done = false;
+  if (C == 19 && sw > 0.f && W >= 4 && (mode == 0 || cs_pix)) {
+    int cols_max = std::min((int)(250.f * sw) - 1, kCW);   // a segment: <= 256 pixels for phase 1, <= 64 columns for phase 2
+    cols_max = cols_max < 1 ? 1 : (cols_max > w ? w : cols_max);
+    const int wcols = (w + (w + cols_max - 1) / cols_max - 1) / ((w + cols_max - 1) / cols_max);   // balanced segments
+    const int wseg = (w + wcols - 1) / wcols;
+    int wspan = 0, taps = 0;
+    for (int sg = 0; sg * wcols < w; ++sg) {
+      int xs, xe, dummy;
+      src_range(sg * wcols, sw, W, xs, dummy);
+      src_range(std::min(w, (sg + 1) * wcols) - 1, sw, W, dummy, xe);
+      xs &= ~3;
+      wspan = std::max(wspan, (xe | 3) + 1 - xs);
+    }
+    for (int jj = 0; jj < w; ++jj) {
+      int lo, hi;
+      src_range(jj, sw, W, lo, hi);
+      taps = std::max(taps, hi - lo + 1);
+    }
+    // rows per block: ONE round of blocks that nearly fills the chip (two 224-register waves per SIMD = 8 blocks per CU); all
+    // blocks do the same work, so a second, partly filled round would cost a whole round's time
+    static const int rows_env = getenv("DASAC_CE_ROWS") ? atoi(getenv("DASAC_CE_ROWS")) : 0;      // experiments only
+    const int slots = (kNumCu - reserved_cus()) * 8;
+    const int chunks_max = std::max(1, slots / std::max(1, B * wseg));
+    const int rows = rows_env > 0 ? rows_env : std::max(4, (H + chunks_max - 1) / chunks_max);
+    const int n_chunks = (H + rows - 1) / rows;
+    const int wpitch = ce_lds_index(wspan - 1) + 2;
+    if (wspan <= 256 && taps <= 24 && (int64_t)B * n_chunks * wseg < (1ll << 31) && (size_t)C * wpitch * sizeof(float) <= 60 * 1024) {
+      const dim3 grid((unsigned)(B * n_chunks * wseg));
+      const size_t wlds = (size_t)C * wpitch * sizeof(float);
+      if (taps <= 20)
+        hipLaunchKernelGGL((ce_bwd_rows_wave<19, 20>), grid, dim3(kCW), wlds, s, logits_up, labels, class_weight, B, H, W, w, sw, mode,
+                           gscale, tmp, wcols, wseg, wpitch, cs_pix, rows, n_chunks);
+      else
+        hipLaunchKernelGGL((ce_bwd_rows_wave<19, 24>), grid, dim3(kCW), wlds, s, logits_up, labels, class_weight, B, H, W, w, sw, mode,
+                           gscale, tmp, wcols, wseg, wpitch, cs_pix, rows, n_chunks);
+      wave_done = true;
+    }
+  }
+  if (wave_done) {
+  } else if (C == 19)
     hipLaunchKernelGGL(ce_bwd_rows<19>, dim3(B * H * n_seg), dim3(kCB), lds, s, logits_up, labels, class_weight, conf, B, C, H, W, w,
                        sw, mode, gscale, tmp, seg_cols, n_seg, pitch, cs_pix);
   else
@@ -1039,9 +1293,11 @@ extern "C" int dasac_warp_pool(const float* probs, const float* theta, const flo
 extern "C" int dasac_warp_back(const float* pooled, const float* mask, const float* theta_inv, int B, int views_per_group,
                                int C, int H, int W, float* refined, dasac_stream_t stream) {
   DASAC_REQUIRE(pooled && mask && theta_inv && refined && B > 0 && views_per_group > 0, "warp_back: bad arguments");
-  const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
+  DASAC_REQUIRE(C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "warp_back: bad shape");
+  const int items = (H + 1) / 2 * W;             // pairs of rows
+  const int per = stream_grid(items, kHB, (kNumCu * 16 + B - 1) / B);
   hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
-                     W, refined, per);
+                     W, refined, per, items, fast_div(W));
   DASAC_CHECK_LAUNCH("warp_back");
   return DASAC_OK;
 }

@@ -258,6 +258,86 @@ __global__ __launch_bounds__(256) void maxpool_bwd(const float* __restrict__ dy,
   }
 }
 
+// The stem pool (3x3, stride 2, padding 1: deeplabv2.py:126) with a 2 x 4 input block per thread -- rows 2p, 2p+1, columns
+// 4q .. 4q+3.  Round 5: the kernel above is ISSUE-bound, not byte-bound (tools/isa_count.py: 306 VALU + 122 SALU instructions per
+// 16 bytes stored = 330 of its 400 us at 16 x 64 x 385^2); this one spends ~1/4 of that per pixel:
+//   * window oh covers input rows 2oh-1 .. 2oh+1, so the block's rows meet window rows p and p+1 only and its columns meet window
+//     columns 2q .. 2q+2: SIX windows per eight pixels (the one-row kernel reads six per four), each read once;
+//   * which (window, argmax code) pairs can name which pixel is known at compile time: row 2p <- (p, a=1); row 2p+1 <- (p, a=2),
+//     (p+1, a=0); column 4q <- (2q, b=1); 4q+1 <- (2q, b=2), (2q+1, b=0); 4q+2 <- (2q+1, b=1); 4q+3 <- (2q+1, b=2), (2q+2, b=0)
+//     -- 18 compare/select/add triples instead of a computed scatter over every pixel of the thread;
+//   * the two index divisions are multiplications (FastDiv).
+// Every pixel adds its candidate windows in the order the kernel above does (window rows ascending, columns ascending, from
+// +0), a window that does not exist or whose pooled value is not positive (ReLU bit) contributes +0: identical bits.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__global__ __launch_bounds__(256) void maxpool_bwd_3s2p1(const float* __restrict__ dy, const uint8_t* __restrict__ arg, int H, int W,
+                                                         int OH, int OW, int relu_mask, float* __restrict__ dx, int items, int Hp,
+                                                         int Wq, FastDiv div_wq, FastDiv div_hp) {
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int rowp = fdiv(it, div_wq), q = it - rowp * Wq;       // rowp = plane * Hp + p
+    const int plane = fdiv(rowp, div_hp), p = rowp - plane * Hp;
+    const int ih = 2 * p, iw0 = 4 * q, ow0 = 2 * q;
+    const size_t ob = (size_t)plane * OH * OW;
+    float d[2][3];
+    int code[2][3];
+    const bool wide = ow0 + 2 < OW;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const bool rok = p + a < OH;
+      const size_t o = ob + (size_t)min(p + a, OH - 1) * OW + ow0;
+      float v[3];
+      int ab[3];
+      if (wide) {
+        const f32x2u v01 = *reinterpret_cast<const f32x2u*>(dy + o);
+        v[0] = v01[0];
+        v[1] = v01[1];
+        v[2] = dy[o + 2];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) ab[b] = arg[o + b];
+      } else {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const size_t ob_ = o + min(b, OW - 1 - ow0);
+          v[b] = dy[ob_];
+          ab[b] = arg[ob_];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const bool ok = rok && ow0 + b < OW && (!relu_mask || (ab[b] & 0x80));
+        d[a][b] = ok ? v[b] : 0.f;
+        code[a][b] = ab[b] & 0x7f;
+      }
+    }
+    auto pick = [&](int a, int ka, int b, int kb) { return code[a][b] == ka * 3 + kb ? d[a][b] : 0.f; };
+    float g0[4], g1[4];
+    // row 2p: window row p with a = 1
+    g0[0] = 0.f + pick(0, 1, 0, 1);
+    g0[1] = (0.f + pick(0, 1, 0, 2)) + pick(0, 1, 1, 0);
+    g0[2] = 0.f + pick(0, 1, 1, 1);
+    g0[3] = (0.f + pick(0, 1, 1, 2)) + pick(0, 1, 2, 0);
+    // row 2p+1: window row p with a = 2, then window row p+1 with a = 0
+    g1[0] = (0.f + pick(0, 2, 0, 1)) + pick(1, 0, 0, 1);
+    g1[1] = (((0.f + pick(0, 2, 0, 2)) + pick(0, 2, 1, 0)) + pick(1, 0, 0, 2)) + pick(1, 0, 1, 0);
+    g1[2] = (0.f + pick(0, 2, 1, 1)) + pick(1, 0, 1, 1);
+    g1[3] = (((0.f + pick(0, 2, 1, 2)) + pick(0, 2, 2, 0)) + pick(1, 0, 1, 2)) + pick(1, 0, 2, 0);
+    float* out = dx + ((size_t)plane * H + ih) * W + iw0;
+    const bool two = ih + 1 < H;
+    if (iw0 + 4 <= W) {
+      *reinterpret_cast<f32x4u*>(out) = f32x4u{g0[0], g0[1], g0[2], g0[3]};
+      if (two) *reinterpret_cast<f32x4u*>(out + W) = f32x4u{g1[0], g1[1], g1[2], g1[3]};
+    } else {
+      const int nx = W - iw0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (e < nx) {
+          out[e] = g0[e];
+          if (two) out[W + e] = g1[e];
+        }
+    }
+  }
+}
+
 // ---- momentum teacher (models/sac.py:83-102) as one multi-tensor launch --------------------------
 // chunk table: for chunk i, tensor id + chunk index.  sq_chunk[i] = sum (slow-fast)^2 over the chunk (pre-update);
 // if update: slow = slow*m + fast*(1-m).
@@ -440,7 +520,12 @@ extern "C" int dasac_maxpool_bwd(const float* dy, const float* y, const uint8_t*
   DASAC_REQUIRE(items < (1ll << 31) && k >= 1 && s >= 1, "maxpool_bwd: tensor too large");
   const dim3 grid(stream_grid(items, 256));
   hipStream_t st = as_stream(stream);
-  if (k == 3 && s == 2) hipLaunchKernelGGL((maxpool_bwd<3, 2>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
+  const int Hp = (H + 1) / 2, Wq = (W + 3) / 4;
+  if (k == 3 && s == 2 && pad == 1 && OH >= 1 && OW >= 1) {
+    const int items2 = planes * Hp * Wq;
+    hipLaunchKernelGGL(maxpool_bwd_3s2p1, dim3(stream_grid(items2, 256)), dim3(256), 0, st, dy, argmax, H, W, OH, OW, relu_mask, dx,
+                       items2, Hp, Wq, fast_div(Wq), fast_div(Hp));
+  } else if (k == 3 && s == 2) hipLaunchKernelGGL((maxpool_bwd<3, 2>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
   else if (k == 2 && s == 2) hipLaunchKernelGGL((maxpool_bwd<2, 2>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
   else if (k == 3 && s == 1) hipLaunchKernelGGL((maxpool_bwd<3, 1>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);
   else hipLaunchKernelGGL((maxpool_bwd<0, 0>), grid, dim3(256), 0, st, dy, y, argmax, H, W, OH, OW, k, s, pad, relu_mask, dx, (int)items);

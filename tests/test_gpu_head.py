@@ -102,6 +102,23 @@ def test_refine_avg_pool_golden_g4(golden):
     assert rel_err(aligned, g["avg_pool_teacher_aligned"]) < TOL
 
 
+@pytest.mark.parametrize("shape", [(4, 19, 21, 30), (2, 5, 22, 9), (2, 19, 1, 7), (6, 2, 33, 64)])
+def test_warp_back_two_rows_per_thread(shape):
+    """warp_back walks the image in pairs of rows (odd and even heights, a single row, odd and even class counts for its
+    two-classes-at-a-time loop): refined[b] = sample(pooled[b // T], theta_inv[b]) * sample(mask[b // T], theta_inv[b])."""
+    from dasac_hip import ops
+    B, C, Hh, W = shape
+    Tn = 2
+    g = torch.Generator().manual_seed(sum(shape))
+    pooled = torch.rand(B // Tn, C, Hh, W, generator=g)
+    mask = (torch.rand(B // Tn, 1, Hh, W, generator=g) > 0.3).float()
+    theta = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]).repeat(B, 1, 1) + 0.25 * torch.randn(B, 2, 3, generator=g)
+    got = ops.warp_back(pooled.cuda(), mask.cuda(), theta.cuda(), Tn)
+    src = pooled.repeat_interleave(Tn, 0)
+    ref = H.warp_affine(src, theta) * H.warp_affine(mask.repeat_interleave(Tn, 0), theta)
+    assert got.shape == ref.shape and rel_err(got, ref) < 2e-5
+
+
 def test_refine_minentropy_pool_golden_g4(golden):
     g = golden("g4_refine")
     refined, chi, _ = _refine_on_gpu(g, "minentropy_pool")
@@ -132,9 +149,9 @@ def test_maxpool_and_relu_masked_backward():
     g = torch.Generator().manual_seed(3)
     # 3x3/2 ceil (the stem pool, deeplabv2.py:126) and 2x2/2 (VGG) take the four-outputs-per-thread kernel: widths that are / are
     # not multiples of 4 outputs, a window row and column hanging over the border (ceil mode), tiny planes; 3x3/1 and 5x5/3 the
-    # one-output kernel
+    # one-output kernel; the backward of 3x3/2 pad 1 is the 2 x 4-pixels-per-thread kernel
     for (k, s, p, ceil, Hh, W) in ((3, 2, 1, True, 33, 41), (2, 2, 0, False, 16, 24), (3, 2, 1, True, 32, 32), (3, 2, 1, True, 7, 5),
-                                   (3, 2, 1, True, 65, 130), (2, 2, 0, False, 9, 11), (3, 1, 1, False, 12, 13), (5, 3, 2, True, 21, 23)):
+                                   (3, 2, 1, True, 65, 130), (3, 2, 1, False, 10, 9), (3, 2, 1, True, 6, 4), (3, 2, 1, False, 2, 38), (2, 2, 0, False, 9, 11), (3, 1, 1, False, 12, 13), (5, 3, 2, True, 21, 23)):
         x = F.relu(torch.randn(2, 5, Hh, W, generator=g)).requires_grad_(True)
         y, idx = F.max_pool2d(x, k, s, p, ceil_mode=ceil, return_indices=True)
         dy = torch.randn(y.shape, generator=g)
@@ -216,8 +233,13 @@ def test_full_size_head_properties():
     assert float((back - same).abs().max()) < 2e-3
 
 
+# 19 classes take the one-wave-per-segment kernel (rows walked by one block, next row prefetched): row ends W % 4 = 0..3 (the
+# rotated last quad), up-factors 1 / 2 / 8, several segments and row chunks; W < 4, B = 1 with confidences, 7 classes and an
+# up-factor of 16 (35 taps) fall back to the block-per-row kernel
 @pytest.mark.parametrize("shape,mode", [((2, 19, 9, 13, 65, 97), 1), ((3, 19, 5, 7, 33, 49), 0), ((2, 19, 97, 97, 769, 769), 1),
-                                        ((1, 7, 4, 6, 8, 12), 1), ((2, 19, 64, 128, 512, 1024), 0)])
+                                        ((1, 7, 4, 6, 8, 12), 1), ((2, 19, 64, 128, 512, 1024), 0), ((2, 19, 5, 6, 38, 46), 1),
+                                        ((2, 19, 7, 9, 50, 71), 0), ((1, 19, 33, 33, 33, 35), 0), ((2, 19, 3, 4, 10, 3), 1),
+                                        ((2, 19, 20, 30, 40, 60), 1), ((1, 19, 5, 5, 65, 65), 0), ((1, 19, 9, 9, 65, 65), 1)])
 def test_ce_backward_straight_into_the_low_resolution_gradient(shape, mode):
     """dasac_ce_loss_bwd_low == dasac_ce_loss(dlogits) followed by dasac_upsample_bwd (the two-kernel path it replaces,
     itself pinned by goldens g3 / g6) -- same weights, same summation order: bit for bit; and autograd through the
