@@ -28,7 +28,7 @@ struct Tap {
   int i0, i1;
   float w0, w1;
 };
-__device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
+__host__ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int n_in) {
   const float src = scale * (float)dst;
   int i0 = (int)src;
   if (i0 > n_in - 1) i0 = n_in - 1;
@@ -60,7 +60,7 @@ __device__ __forceinline__ float* at_off(float* base, unsigned byte_off) {
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 template <int CT, bool SOFTMAX, bool NARROW>
-__global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict__ x, int Crt, int h, int w, int H, int W,
+__global__ __launch_bounds__(kHB, (SOFTMAX && NARROW) ? 4 : 1) void upsample_softmax(const float* __restrict__ x, int Crt, int h, int w, int H, int W,
                                                         float sh, float sw, const uint8_t* __restrict__ ignore,
                                                         float* __restrict__ up, float* __restrict__ probs,
                                                         unsigned long long* __restrict__ csum, int items, FastDiv div_wq) {
@@ -109,8 +109,12 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
         const float* pl = xb + (size_t)c * hw;
         float val[4];
         if (narrow) {
+#ifdef DASAC_EXP_UP_NOLOAD
+          const float t0 = sh + c, t1 = sw + c, t2 = t0 * 1.5f, b0 = t1 * 0.5f, b1 = t0 + t1, b2 = t0 - t1;
+#else
           const float t0 = ld_off(pl, a00), t1 = ld_off(pl, a01), t2 = ld_off(pl, a02);
           const float b0 = ld_off(pl, a10), b1 = ld_off(pl, a11), b2 = ld_off(pl, a12);
+#endif
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float ta = hi[e] ? t1 : t0, tb = hi[e] ? t2 : t1;
@@ -168,7 +172,11 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < CT; ++c)
           if (c < C) {
+#ifdef DASAC_EXP_UP_NOEXP
+            v[e][c] = v[e][c] - mx[e];
+#else
             v[e][c] = expf(v[e][c] - mx[e]);
+#endif
             den += v[e][c];
           }
         inv[e] = 1.f / den;
@@ -184,7 +192,11 @@ __global__ __launch_bounds__(kHB) void upsample_softmax(const float* __restrict_
             if (e < nx) acc[c] += pr[e];
             if (ign[e]) pr[e] = 0.f;
           }
+#ifdef DASAC_EXP_UP_NOSTORE
+          if (probs && pr[0] == 1.2345e-30f) {
+#else
           if (probs) {
+#endif
             float* o = at_off(probs + obase + (size_t)c * HW, ooff);
             if (nx == 4) {
               *reinterpret_cast<f32x4u*>(o) = f32x4u{pr[0], pr[1], pr[2], pr[3]};
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(kHB) void infer_labels(const float* __restrict__ x,
 // ---- transpose of the bilinear upsampling, separable and gather-based (deterministic) ---------
 // pass X: tmp[plane][y][j] = sum_x wx(x->j) * g[plane][y][x]          (reads the big gradient once)
 // pass Y: d[plane][i][j]   = gscale * sum_y wy(y->i) * tmp[plane][y][j]
-__device__ __forceinline__ float weight_to(int dst, float scale, int n_in, int target) {
+__host__ __device__ __forceinline__ float weight_to(int dst, float scale, int n_in, int target) {
   const Tap t = tap_ac(dst, scale, n_in);
   float wgt = 0.f;
   if (t.i0 == target) wgt += t.w0;
@@ -638,6 +650,11 @@ __global__ __launch_bounds__(kCB) void ce_bwd_rows(const float* __restrict__ xup
 //   * a thread keeps its column's SPAN tap weights and LDS indices in registers for all rows;
 //   * a one-wave block needs no cross-wave barrier, and seven of them fit a CU (22 KB of LDS each).
 // Per pixel and per column the arithmetic and its order are those of ce_bwd_rows: identical bits.
+__host__ __device__ __forceinline__ void ce_taps(int j, float sw, int W, int w, int& lo, int& hi) {
+  src_range(j, sw, W, lo, hi);
+  while (lo < hi && weight_to(lo, sw, w, j) == 0.f) ++lo;
+  while (hi > lo && weight_to(hi, sw, w, j) == 0.f) --hi;
+}
 constexpr int kCW = 64;
 typedef long long i64x2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int CT, int SPAN>
@@ -669,16 +686,21 @@ __global__ __launch_bounds__(kCW, 2) void ce_bwd_rows_wave(const float* __restri
   const int groups = max(1, min(CT, kCW / nj));
   const bool red = (int)threadIdx.x < nj * groups;
   const int j = j0 + (int)threadIdx.x % nj, g0 = (int)threadIdx.x / nj;
+  // its taps: src_range is generous by two positions on either side; the zero weights at both ends are dropped, and the slots
+  // behind the last tap (up to SPAN) carry weight 0 on that tap's LDS index.  acc starts at +0 and can never become -0, so
+  // adding 0 * (a finite gradient) anywhere leaves every bit of the sum as it is: no predicate on the accumulation.
   int lo, hi;
-  src_range(j, sw, W, lo, hi);
+  ce_taps(j, sw, W, w, lo, hi);
   const int n = hi - lo + 1;                              // <= SPAN (launcher)
   float wt[SPAN];
-  int li[SPAN];
+  unsigned la[SPAN];                                      // LDS byte offsets inside a class row
 #pragma unroll
   for (int i = 0; i < SPAN; ++i) {
     wt[i] = i < n ? weight_to(lo + i, sw, w, j) : 0.f;
-    li[i] = ce_lds_index(min(lo + i, hi) - xs);
+    la[i] = (unsigned)ce_lds_index(min(lo + i, hi) - xs) * 4u;
   }
+  const unsigned row_bytes = (unsigned)pitch * 4u;
+  float* const tmp_col = tmp + ((size_t)b * CT * H) * w + j;  // + (c * H + oy) * w
   __shared__ float s_cw[CT];                              // class weights: an LDS lookup by label, not a dependent global load
   if (threadIdx.x < CT) s_cw[threadIdx.x] = cw ? cw[threadIdx.x] : 1.f;
   __syncthreads();
@@ -726,7 +748,11 @@ __global__ __launch_bounds__(kCW, 2) void ce_bwd_rows_wave(const float* __restri
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+#ifdef DASAC_EXP_CE_NOEXP
+          v[c][e] = v[c][e] - mx[e];
+#else
           v[c][e] = expf(v[c][e] - mx[e]);
+#endif
           den[e] += v[c][e];
         }
       float k[4], gw[4];
@@ -744,19 +770,22 @@ __global__ __launch_bounds__(kCW, 2) void ce_bwd_rows_wave(const float* __restri
         for (int e = 0; e < 4; ++e) wr[c * pitch + e] = k[e] * v[c][e] - ((c == lb[e]) ? gw[e] : 0.f);
     }
     __builtin_amdgcn_sched_barrier(0);                    // not earlier: the next row reuses this row's 76 registers
+#ifndef DASAC_EXP_CE_NOLOAD
     if (oy + 1 < y1) load_row(oy + 1);                    // in flight while this row is reduced
+#endif
     __syncthreads();
+#ifdef DASAC_EXP_CE_NOP2
+    if (red && sw == 123.f) {
+#else
     if (red) {
+#endif
 #pragma unroll 1
       for (int c = g0; c < CT; c += groups) {
-        const float* row = s_d + c * pitch;
+        const char* row = reinterpret_cast<const char*>(s_d) + (unsigned)c * row_bytes;
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < SPAN; ++i) {
-          const float t = acc + wt[i] * row[li[i]];
-          acc = i < n ? t : acc;                            // a select, not a branch per tap
-        }
-        tmp[((size_t)(b * CT + c) * H + oy) * w + j] = acc;
+        for (int i = 0; i < SPAN; ++i) acc += wt[i] * *reinterpret_cast<const float*>(row + la[i]);
+        tmp_col[(unsigned)(c * H + oy) * (unsigned)w] = acc;
       }
     }
     __syncthreads();
@@ -956,10 +985,15 @@ __global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ p
 // 213 us at 8 x 19 x 769^2: the registers of 76 gathers in flight cost more occupancy than the batching wins; the class loop stays)
 // Round 5: a thread owns the pixel (2r, x) AND the one below it.  The counters showed 2.4x the algorithmic bytes entering L2: the
 // row below re-reads the lower source row of the row above, and in the linear pixel order that neighbour is another block on
-// another XCD (its own L2).  With both rows in one thread the shared source row is fetched once per row PAIR, and a class has
-// eight independent taps in flight instead of four (the loop was latency-bound: 22 VALU instructions per class, 4 gathers).
-// The block still walks the pair-of-rows plane linearly, so the 2 x 19 store streams stay sequential in DRAM; per pixel the same
-// make_sample / take arithmetic: identical bits.  Class planes are scalar bases + 32-bit per-lane byte offsets.
+// another XCD (its own L2).  With both rows in one thread the shared source row is fetched once per row PAIR, and two classes'
+// sixteen taps are in flight instead of four.  The block still walks the pair-of-rows plane linearly, so the 2 x 19 store
+// streams stay sequential in DRAM; per pixel the same make_sample / take arithmetic: identical bits.  Class planes are scalar
+// bases + 32-bit per-lane byte offsets.  Same-box A/B against the one-row kernel (tools/head_exp.py, three pairs): 204 / 215 /
+// 205 us against 214 / 232 / 215 at 8 x 19 x 769^2 -- 5 %; the kernel stays bound by its gathers' latency.
+// (Measured and rejected on the way: four horizontally adjacent pixels per thread with dwordx4 stores 364 us -- gathers whose
+// lanes sit 16 bytes apart; an XCD-aware chunk order (XCD x walks the x-th eighth of every pass, so that vertical neighbours
+// share an L2) 224 against 208 us here and 445 against 311 us for warp_pool: what these kernels need is the linear pixel
+// order's sequential DRAM streams, not fewer L2 fills.)
 __device__ __forceinline__ float take_off(const float* __restrict__ pl, const Sample& s) {
   return ld_off(pl, (unsigned)s.o00 * 4u) * s.w00 + ld_off(pl, (unsigned)s.o01 * 4u) * s.w01 + ld_off(pl, (unsigned)s.o10 * 4u) * s.w10 +
          ld_off(pl, (unsigned)s.o11 * 4u) * s.w11;
@@ -1225,7 +1259,7 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
     }
     for (int jj = 0; jj < w; ++jj) {
       int lo, hi;
-      src_range(jj, sw, W, lo, hi);
+      ce_taps(jj, sw, W, w, lo, hi);
       taps = std::max(taps, hi - lo + 1);
     }
     // rows per block: ONE round of blocks that nearly fills the chip (two 224-register waves per SIMD = 8 blocks per CU); all
@@ -1239,8 +1273,8 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
     if (wspan <= 256 && taps <= 24 && (int64_t)B * n_chunks * wseg < (1ll << 31) && (size_t)C * wpitch * sizeof(float) <= 60 * 1024) {
       const dim3 grid((unsigned)(B * n_chunks * wseg));
       const size_t wlds = (size_t)C * wpitch * sizeof(float);
-      if (taps <= 20)
-        hipLaunchKernelGGL((ce_bwd_rows_wave<19, 20>), grid, dim3(kCW), wlds, s, logits_up, labels, class_weight, B, H, W, w, sw, mode,
+      if (taps <= 16)
+        hipLaunchKernelGGL((ce_bwd_rows_wave<19, 16>), grid, dim3(kCW), wlds, s, logits_up, labels, class_weight, B, H, W, w, sw, mode,
                            gscale, tmp, wcols, wseg, wpitch, cs_pix, rows, n_chunks);
       else
         hipLaunchKernelGGL((ce_bwd_rows_wave<19, 24>), grid, dim3(kCW), wlds, s, logits_up, labels, class_weight, B, H, W, w, sw, mode,

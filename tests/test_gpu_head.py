@@ -103,9 +103,9 @@ def test_refine_avg_pool_golden_g4(golden):
 
 
 @pytest.mark.parametrize("shape", [(4, 19, 21, 30), (2, 5, 22, 9), (2, 19, 1, 7), (6, 2, 33, 64)])
-def test_warp_back_two_rows_per_thread(shape):
-    """warp_back walks the image in pairs of rows (odd and even heights, a single row, odd and even class counts for its
-    two-classes-at-a-time loop): refined[b] = sample(pooled[b // T], theta_inv[b]) * sample(mask[b // T], theta_inv[b])."""
+def test_warp_back_against_the_oracle(shape):
+    """refined[b] = sample(pooled[b // T], theta_inv[b]) * sample(mask[b // T], theta_inv[b]) under random affines (odd and even
+    heights, a single row, few classes)."""
     from dasac_hip import ops
     B, C, Hh, W = shape
     Tn = 2

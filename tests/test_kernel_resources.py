@@ -82,3 +82,29 @@ def test_hot_gemm_loops_have_no_scratch_fit_their_occupancy_and_keep_their_instr
             other = [l for l in body[h:j + 1] if l.strip() and not l.strip().startswith(";") and not re.match(r"^\.LBB", l.strip())
                      and "v_mfma" not in l]
             assert len(other) * 32.0 / n <= diet, (key, len(other), n)
+
+
+# The streaming head kernels are issue-bound (tools/isa_count.py, profiles/EXPERIMENTS.md round 5): their occupancy arguments and
+# instruction diets are part of the design.  name fragment -> (VGPR budget, scratch bytes budget, VALU instructions in the kernel)
+HEAD = {
+    "upsample_softmaxILi19ELb1ELb1EEE": (128, 32, 3400),      # probs path, up-factor 8: four waves per SIMD (was 225 VGPRs, ~4600 VALU)
+    "upsample_softmaxILi19ELb0ELb1EEE": (64, 0, 1300),        # logits only: eight waves per SIMD (was 102 VGPRs, ~2500 VALU)
+    "ce_bwd_rows_waveILi19ELi16EEE": (256, 0, 2800),          # two waves per SIMD, nothing spilled inside the row loop
+}
+POOL = {"maxpool_bwd_3s2p1": (64, 0, 200)}                    # 2 x 4 pixels per thread: ~170 VALU per 8 pixels (306 per 4 before)
+
+
+@pytest.mark.parametrize("src,table", [("head", HEAD), ("pointwise", POOL)])
+def test_streaming_head_kernels_keep_their_registers_and_instruction_counts(tmp_path, src, table):
+    txt = _asm(tmp_path, src)
+    meta = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in re.finditer(
+        r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size: (\d+)\n(?:.*\n){0,8}?\s+\.vgpr_count:\s+(\d+)", txt)}
+    for key, (vgpr_budget, scratch_budget, valu_budget) in table.items():
+        names = [n for n in meta if key in n]
+        assert len(names) == 1, (key, names)
+        scratch, vgprs = meta[names[0]]
+        assert vgprs <= vgpr_budget and scratch <= scratch_budget, (key, vgprs, scratch)
+        body = txt[txt.index("\n" + names[0] + ":"):]
+        body = body[:body.index("s_endpgm")].split("\n")
+        valu = sum(1 for l in body if l.strip().startswith("v_"))
+        assert valu <= valu_budget, (key, valu)

@@ -29,25 +29,34 @@ up, probs, _ = ops.upsample_softmax(low, (H, H), ign, want_probs=True)
 y = torch.randint(0, C, (B, H, H), device="cuda")
 conf = torch.rand(B, 1, H, H, device="cuda")
 cw = torch.rand(C, device="cuda")
+ONLY = os.environ.get("HEAD_BW_ONLY", "")        # substring filter (tools/head_exp.py times one kernel through variant libraries)
 rows = []
-rows.append(("upsample_softmax (logits_up)", T, timeit(lambda: ops.upsample_softmax(low, (H, H)))))
-rows.append(("upsample_softmax (probs+sums+mask)", T + P, timeit(lambda: ops.upsample_softmax(low, (H, H), ign, want_up=False, want_probs=True, want_sums=True))))
-rows.append(("ce_loss forward (focal+conf)", T + P * 12, timeit(lambda: ops.ce_loss(up, y, cw, conf))))
-rows.append(("ce_loss backward -> low-res (fused)", T + P * 12, timeit(lambda: ops.ce_loss_bwd_low(up, y, (h, h), cw, conf))))
-rows.append(("ce_loss dlogits + upsample_bwd (old path)", 3 * T + P * 12, timeit(lambda: ops.upsample_bwd(ops.ce_loss(up, y, cw, conf, want_grad=True)[1], (h, h)))))
-rows.append(("pseudo_labels", T + P * (1 + 8 + 4), timeit(lambda: ops.pseudo_labels(probs, ign, 0.75, 0.2, cw))))
+
+
+def row(name, nbytes, fn):
+    if ONLY in name:
+        rows.append((name, nbytes, timeit(fn)))
+
+
+row("upsample_softmax (logits_up)", T, lambda: ops.upsample_softmax(low, (H, H)))
+row("upsample_softmax (probs+sums+mask)", T + P, lambda: ops.upsample_softmax(low, (H, H), ign, want_up=False, want_probs=True, want_sums=True))
+row("ce_loss forward (focal+conf)", T + P * 12, lambda: ops.ce_loss(up, y, cw, conf))
+row("ce_loss backward -> low-res (fused)", T + P * 12, lambda: ops.ce_loss_bwd_low(up, y, (h, h), cw, conf))
+row("ce_loss dlogits + upsample_bwd (old path)", 3 * T + P * 12, lambda: ops.upsample_bwd(ops.ce_loss(up, y, cw, conf, want_grad=True)[1], (h, h)))
+row("pseudo_labels", T + P * (1 + 8 + 4), lambda: ops.pseudo_labels(probs, ign, 0.75, 0.2, cw))
 theta, inv = driver.view_affines(driver.BENCH_VIEWS, H, H)
 theta, inv = theta.repeat(2, 1, 1).cuda(), inv.repeat(2, 1, 1).cuda()
-rows.append(("warp_pool (T=4, +aligned)", 2 * T + T // 4, timeit(lambda: ops.warp_pool(probs, theta, inv, 4))))
+row("warp_pool (T=4, +aligned)", 2 * T + T // 4, lambda: ops.warp_pool(probs, theta, inv, 4))
 pooled, mask, _ = ops.warp_pool(probs, theta, inv, 4)
-rows.append(("warp_back", T // 4 + T, timeit(lambda: ops.warp_back(pooled, mask, inv, 4))))
+row("warp_back", T // 4 + T, lambda: ops.warp_back(pooled, mask, inv, 4))
 x = torch.randn(B, 64, 385, 385, device="cuda")
 yp, arg = ops.maxpool_fwd(x, 3, 2, 1, True)
 dy = torch.randn_like(yp)
-rows.append(("maxpool_fwd 3x3/2 ceil", x.numel() * 4 + yp.numel() * 5, timeit(lambda: ops.maxpool_fwd(x, 3, 2, 1, True))))
-rows.append(("maxpool_bwd (+ReLU mask)", x.numel() * 4 + yp.numel() * 5, timeit(lambda: ops.maxpool_bwd(dy, yp, arg, (385, 385), 3, 2, 1, True))))
+row("maxpool_fwd 3x3/2 ceil", x.numel() * 4 + yp.numel() * 5, lambda: ops.maxpool_fwd(x, 3, 2, 1, True))
+row("maxpool_bwd (+ReLU mask)", x.numel() * 4 + yp.numel() * 5, lambda: ops.maxpool_bwd(dy, yp, arg, (385, 385), 3, 2, 1, True))
 a = torch.randn(B, 1024, 97, 97, device="cuda")
-rows.append(("relu_mask", 3 * a.numel() * 4, timeit(lambda: ops.relu_mask(a, a))))
-print("{:44s} {:>9s} {:>9s} {:>8s} {:>7s}".format("kernel", "MB", "us", "TB/s", "of 8"))
+row("relu_mask", 3 * a.numel() * 4, lambda: ops.relu_mask(a, a))
+if not ONLY:
+    print("{:44s} {:>9s} {:>9s} {:>8s} {:>7s}".format("kernel", "MB", "us", "TB/s", "of 8"))
 for name, nbytes, t in rows:
     print("{:44s} {:9.1f} {:9.1f} {:8.2f} {:6.0f}%".format(name, nbytes / 1e6, t * 1e6, nbytes / t / 1e12, 100 * nbytes / t / 8e12))
