@@ -938,65 +938,157 @@ __global__ __launch_bounds__(kHB) void warp_pool(const float* __restrict__ probs
 // loads for T = 4; the unrolled class loop lets the compiler run several classes ahead).  Same arithmetic in the same order
 // (per class S = ((a0*cov0 + a1*cov1) + a2*cov2) + a3*cov3 accumulated from 0 in view order, then Z, mask, S / max(Z, 1e-3)):
 // bit-identical to the generic kernel, which stays for min-entropy pooling, pre-aligned views, T > 4 and other class counts.
+// Round 5: every plane base is a scalar (group pointer + compile-time (view, class) offset) and the pixel a 32-bit lane offset --
+// no 64-bit per-lane address arithmetic in front of the 16 gathers and 4 stores of a class: 2054 instead of 2672 VALU instructions
+// per pixel, 325 -> 235 us at 2 x 4 x 19 x 769^2 (same box, tools/head_exp.py).  DASAC_WP_ROWS vertically adjacent pixels per
+// thread (the row below shares a source row: fewer L2 fills, as in warp_back): 2 rows need 256 VGPRs and run 566 us -- one row.
+#ifndef DASAC_WP_ROWS
+#define DASAC_WP_ROWS 1
+#endif
+constexpr int kWpRows = DASAC_WP_ROWS;
+__device__ __forceinline__ float take_off(const float* __restrict__ pl, const Sample& s) {
+  return ld_off(pl, (unsigned)s.o00 * 4u) * s.w00 + ld_off(pl, (unsigned)s.o01 * 4u) * s.w01 + ld_off(pl, (unsigned)s.o10 * 4u) * s.w10 +
+         ld_off(pl, (unsigned)s.o11 * 4u) * s.w11;
+}
+template <int CT, int TT, int R>
+__device__ __forceinline__ void warp_pool_rows(const float* __restrict__ probs_n, const float* __restrict__ theta_n,
+                                               const float* __restrict__ theta_inv_n, int H, int W, int HW, float tol,
+                                               float* __restrict__ aligned_n, float* __restrict__ pooled_n,
+                                               float* __restrict__ mask_n, int oy, int ox) {
+  Sample s[R][TT];
+  float cov[R][TT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      s[r][t] = make_sample(theta_n + t * 6, oy + r, ox, H, W);
+      const Sample si = make_sample(theta_inv_n + t * 6, oy + r, ox, H, W);
+      cov[r][t] = si.w00 + si.w01 + si.w10 + si.w11;
+    }
+  const unsigned o0 = (unsigned)(oy * W + ox) * 4u, pitch = (unsigned)W * 4u;
+  float S[R][CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    float a[R][TT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) a[r][t] = take_off(probs_n + (size_t)(t * CT + c) * HW, s[r][t]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (aligned_n) *at_off(aligned_n + (size_t)(t * CT + c) * HW, o0 + (unsigned)r * pitch) = a[r][t];
+        acc += a[r][t] * cov[r][t];
+      }
+      S[r][c] = acc;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float Z = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) Z += S[r][c];
+    const float den = fmaxf(Z, 1e-3f);
+    *at_off(mask_n, o0 + (unsigned)r * pitch) = Z > tol ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) *at_off(pooled_n + (size_t)c * HW, o0 + (unsigned)r * pitch) = S[r][c] / den;
+  }
+}
 template <int CT, int TT>
 __global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ probs, const float* __restrict__ theta,
                                                      const float* __restrict__ theta_inv, int H, int W, float tol,
                                                      float* __restrict__ aligned, float* __restrict__ pooled,
-                                                     float* __restrict__ mask, int blocks_per_group) {
+                                                     float* __restrict__ mask, int blocks_per_group, int items, FastDiv div_w) {
   const int n = blockIdx.x / blocks_per_group, chunk = blockIdx.x % blocks_per_group;
   const int HW = H * W;
-  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_group * kHB) {
-    const int oy = p / W, ox = p - oy * W;
-    Sample s[TT];
-    float cov[TT];
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      const int b = n * TT + t;
-      s[t] = make_sample(theta + b * 6, oy, ox, H, W);
-      const Sample si = make_sample(theta_inv + b * 6, oy, ox, H, W);
-      cov[t] = si.w00 + si.w01 + si.w10 + si.w11;
+  const float* probs_n = probs + (size_t)n * TT * CT * HW;
+  float* aligned_n = aligned ? aligned + (size_t)n * TT * CT * HW : nullptr;
+  float* pooled_n = pooled + (size_t)n * CT * HW;
+  float* mask_n = mask + (size_t)n * HW;
+  const float* th = theta + n * TT * 6;
+  const float* thi = theta_inv + n * TT * 6;
+  for (int it = chunk * kHB + threadIdx.x; it < items; it += blocks_per_group * kHB) {
+    const int rr = fdiv(it, div_w), ox = it - rr * W;
+    const int oy = kWpRows * rr;
+    if (oy + kWpRows <= H) {
+      warp_pool_rows<CT, TT, kWpRows>(probs_n, th, thi, H, W, HW, tol, aligned_n, pooled_n, mask_n, oy, ox);
+    } else {
+      for (int y = oy; y < H; ++y) warp_pool_rows<CT, TT, 1>(probs_n, th, thi, H, W, HW, tol, aligned_n, pooled_n, mask_n, y, ox);
     }
-    float S[CT];
-    float Z = 0.f;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      float a[TT];
-#pragma unroll
-      for (int t = 0; t < TT; ++t) a[t] = take(probs + ((size_t)(n * TT + t) * CT + c) * HW, s[t]);
-      float acc = 0.f;
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        if (aligned) aligned[((size_t)(n * TT + t) * CT + c) * HW + p] = a[t];
-        acc += a[t] * cov[t];
-      }
-      S[c] = acc;
-    }
-#pragma unroll
-    for (int c = 0; c < CT; ++c) Z += S[c];
-    const float den = fmaxf(Z, 1e-3f);
-    mask[(size_t)n * HW + p] = Z > tol ? 1.f : 0.f;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) pooled[((size_t)n * CT + c) * HW + p] = S[c] / den;
   }
 }
 
 // refined[b] = sample(pooled[g(b)], theta_inv[b]) * sample(mask[g(b)], theta_inv[b]),  g(b) = group_of[b]
 // (round 4, measured: a compile-time class count with all 4 x 19 taps of a pixel in flight makes this kernel SLOWER -- 327 vs
 // 213 us at 8 x 19 x 769^2: the registers of 76 gathers in flight cost more occupancy than the batching wins; the class loop stays)
-// Round 5: a thread owns the pixel (2r, x) AND the one below it.  The counters showed 2.4x the algorithmic bytes entering L2: the
+// Round 5: a thread owns kWbRows vertically adjacent pixels.  The counters showed 2.4x the algorithmic bytes entering L2: the
 // row below re-reads the lower source row of the row above, and in the linear pixel order that neighbour is another block on
-// another XCD (its own L2).  With both rows in one thread the shared source row is fetched once per row PAIR, and two classes'
-// sixteen taps are in flight instead of four.  The block still walks the pair-of-rows plane linearly, so the 2 x 19 store
-// streams stay sequential in DRAM; per pixel the same make_sample / take arithmetic: identical bits.  Class planes are scalar
-// bases + 32-bit per-lane byte offsets.  Same-box A/B against the one-row kernel (tools/head_exp.py, three pairs): 204 / 215 /
-// 205 us against 214 / 232 / 215 at 8 x 19 x 769^2 -- 5 %; the kernel stays bound by its gathers' latency.
+// another XCD (its own L2).  With the rows in one thread a shared source row is fetched once per group of rows, and sixteen
+// taps are in flight instead of four.  The block still walks the plane of row groups linearly, so the store streams stay
+// sequential in DRAM; per pixel the same make_sample / take arithmetic: identical bits.  Class planes are scalar
+// bases + 32-bit per-lane byte offsets.  Same-box A/B of two rows against the one-row kernel (tools/head_exp.py, three pairs):
+// 204 / 215 / 205 us against 214 / 232 / 215 at 8 x 19 x 769^2.  L2 fills per launch (FETCH_SIZE x 2): 687 MB with one row, 568
+// with two, 503 with four (kWbRows) against 360 MB for one pass per view; kernel time 217 / 208 / 202 us.  Knock-outs: without
+// its stores 130 us, without its gathers 91 us, without both 32 us -- 130 + 91 = the kernel: loads and stores do not overlap,
+// the launch moves ~880 MB through the L2-fabric path at ~4.4 TB/s whichever way the bytes go.
 // (Measured and rejected on the way: four horizontally adjacent pixels per thread with dwordx4 stores 364 us -- gathers whose
 // lanes sit 16 bytes apart; an XCD-aware chunk order (XCD x walks the x-th eighth of every pass, so that vertical neighbours
 // share an L2) 224 against 208 us here and 445 against 311 us for warp_pool: what these kernels need is the linear pixel
 // order's sequential DRAM streams, not fewer L2 fills.)
-__device__ __forceinline__ float take_off(const float* __restrict__ pl, const Sample& s) {
-  return ld_off(pl, (unsigned)s.o00 * 4u) * s.w00 + ld_off(pl, (unsigned)s.o01 * 4u) * s.w01 + ld_off(pl, (unsigned)s.o10 * 4u) * s.w10 +
-         ld_off(pl, (unsigned)s.o11 * 4u) * s.w11;
+#ifndef DASAC_WB_ROWS
+#define DASAC_WB_ROWS 4
+#endif
+constexpr int kWbRows = DASAC_WB_ROWS;       // vertically adjacent output pixels per thread
+// R rows of one output column: R sample descriptors, then the classes NC at a time with all NC * R * 4 taps issued before the
+// first is used (R, NC compile-time: as run-time predicates the compiler sinks the lower rows' taps under their test and waits
+// for four loads at a time).
+template <int R>
+__device__ __forceinline__ void warp_back_rows(const float* __restrict__ pooled_n, const float* __restrict__ mask_n,
+                                               const float* __restrict__ th, float* __restrict__ refined_b, int C, int H, int W,
+                                               int HW, int oy, int ox) {
+  Sample s[R];
+  float mv[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    s[r] = make_sample(th, oy + r, ox, H, W);
+    mv[r] = take_off(mask_n, s[r]);
+  }
+  const unsigned o0 = (unsigned)(oy * W + ox) * 4u, pitch = (unsigned)W * 4u;
+  auto batch = [&](int c, auto nc_tag) {
+    constexpr int NC = decltype(nc_tag)::value;
+    float t[NC][R][4];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const float* pl = pooled_n + (size_t)(c + u) * HW;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#ifdef DASAC_EXP_WB_NOLOAD
+        t[u][r][0] = s[r].w00 + c; t[u][r][1] = s[r].w01 + u; t[u][r][2] = s[r].w10 - c; t[u][r][3] = s[r].w11 * 2.f;
+#else
+        t[u][r][0] = ld_off(pl, (unsigned)s[r].o00 * 4u); t[u][r][1] = ld_off(pl, (unsigned)s[r].o01 * 4u);
+        t[u][r][2] = ld_off(pl, (unsigned)s[r].o10 * 4u); t[u][r][3] = ld_off(pl, (unsigned)s[r].o11 * 4u);
+#endif
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      float* out = refined_b + (size_t)(c + u) * HW;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float a = t[u][r][0] * s[r].w00 + t[u][r][1] * s[r].w01 + t[u][r][2] * s[r].w10 + t[u][r][3] * s[r].w11;
+#ifdef DASAC_EXP_WB_NOSTORE
+        if (a == 1.2345e-30f)
+#endif
+        *at_off(out, o0 + (unsigned)r * pitch) = a * mv[r];
+      }
+    }
+  };
+  constexpr int NCB = R >= 4 ? 1 : 2;           // 16 taps in flight either way
+  int c = 0;
+  for (; c + NCB <= C; c += NCB) batch(c, std::integral_constant<int, NCB>{});
+  for (; c < C; ++c) batch(c, std::integral_constant<int, 1>{});
 }
 __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ pooled, const float* __restrict__ mask,
                                                  const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
@@ -1004,49 +1096,17 @@ __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ poole
   const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
   const int n = b / group_div;
   const int HW = H * W;
+  const float* pooled_n = pooled + (size_t)n * C * HW;
+  const float* mask_n = mask + (size_t)n * HW;
+  float* refined_b = refined + (size_t)b * C * HW;
   for (int it = chunk * kHB + threadIdx.x; it < items; it += blocks_per_image * kHB) {
     const int r = fdiv(it, div_w), ox = it - r * W;
-    const int oy = 2 * r;
-    const Sample s0 = make_sample(theta_inv + b * 6, oy, ox, H, W);
-    const float* mp = mask + (size_t)n * HW;
-    const float mv0 = take_off(mp, s0);
-    const unsigned o0 = (unsigned)(oy * W + ox) * 4u, o1 = o0 + (unsigned)W * 4u;
-    // classes two at a time, all their taps issued before the first is used.  `two` (a second row exists: everywhere but on the
-    // last row of an odd H) is a compile-time tag -- as a run-time predicate the compiler sinks the second row's taps under it
-    // and waits for four loads at a time.
-    auto rows = [&](auto two_tag) {
-      constexpr bool TWO = decltype(two_tag)::value;
-      const Sample s1 = TWO ? make_sample(theta_inv + b * 6, oy + 1, ox, H, W) : s0;
-      const float mv1 = TWO ? take_off(mp, s1) : 0.f;
-      auto batch = [&](int c, auto nc_tag) {
-        constexpr int NC = decltype(nc_tag)::value;
-        float t0[NC][4], t1[NC][4];
-#pragma unroll
-        for (int u = 0; u < NC; ++u) {
-          const float* pl = pooled + ((size_t)n * C + c + u) * HW;
-          t0[u][0] = ld_off(pl, (unsigned)s0.o00 * 4u); t0[u][1] = ld_off(pl, (unsigned)s0.o01 * 4u);
-          t0[u][2] = ld_off(pl, (unsigned)s0.o10 * 4u); t0[u][3] = ld_off(pl, (unsigned)s0.o11 * 4u);
-          if (TWO) {
-            t1[u][0] = ld_off(pl, (unsigned)s1.o00 * 4u); t1[u][1] = ld_off(pl, (unsigned)s1.o01 * 4u);
-            t1[u][2] = ld_off(pl, (unsigned)s1.o10 * 4u); t1[u][3] = ld_off(pl, (unsigned)s1.o11 * 4u);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < NC; ++u) {
-          float* out = refined + ((size_t)b * C + c + u) * HW;
-          const float a0 = t0[u][0] * s0.w00 + t0[u][1] * s0.w01 + t0[u][2] * s0.w10 + t0[u][3] * s0.w11;
-          *at_off(out, o0) = a0 * mv0;
-          if (TWO) {
-            const float a1 = t1[u][0] * s1.w00 + t1[u][1] * s1.w01 + t1[u][2] * s1.w10 + t1[u][3] * s1.w11;
-            *at_off(out, o1) = a1 * mv1;
-          }
-        }
-      };
-      int c = 0;
-      for (; c + 2 <= C; c += 2) batch(c, std::integral_constant<int, 2>{});
-      if (c < C) batch(c, std::integral_constant<int, 1>{});
-    };
-    if (oy + 1 < H) rows(std::true_type{}); else rows(std::false_type{});
+    const int oy = kWbRows * r;
+    if (oy + kWbRows <= H) {
+      warp_back_rows<kWbRows>(pooled_n, mask_n, theta_inv + b * 6, refined_b, C, H, W, HW, oy, ox);
+    } else {                                    // the last rows of a height that is no multiple of kWbRows
+      for (int y = oy; y < H; ++y) warp_back_rows<1>(pooled_n, mask_n, theta_inv + b * 6, refined_b, C, H, W, HW, y, ox);
+    }
   }
 }
 
@@ -1310,9 +1370,12 @@ extern "C" int dasac_warp_pool(const float* probs, const float* theta, const flo
                                dasac_stream_t stream) {
   DASAC_REQUIRE(probs && pooled && mask && ((theta && theta_inv) || (!theta && !theta_inv && !aligned)), "warp_pool: null pointer");
   DASAC_REQUIRE(N > 0 && T > 0 && C > 0 && C <= kMaxC && (mode == 0 || mode == 1), "warp_pool: bad arguments");
+  DASAC_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "warp_pool: bad shape");
   const int per = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + N - 1) / N);
   hipStream_t s = as_stream(stream);
-#define DASAC_WPA(TT) hipLaunchKernelGGL((warp_pool_avg<19, TT>), dim3(per * N), dim3(kHB), 0, s, probs, theta, theta_inv, H, W, tolerance, aligned, pooled, mask, per)
+  const int items_r = (H + kWpRows - 1) / kWpRows * W;
+  const int per_r = stream_grid(items_r, kHB, (kNumCu * 16 + N - 1) / N);
+#define DASAC_WPA(TT) hipLaunchKernelGGL((warp_pool_avg<19, TT>), dim3(per_r * N), dim3(kHB), 0, s, probs, theta, theta_inv, H, W, tolerance, aligned, pooled, mask, per_r, items_r, fast_div(W))
   if (mode == 0 && theta && C == 19 && T == 4) DASAC_WPA(4);
   else if (mode == 0 && theta && C == 19 && T == 2) DASAC_WPA(2);
   else if (mode == 0 && theta && C == 19 && T == 1) DASAC_WPA(1);
@@ -1328,7 +1391,7 @@ extern "C" int dasac_warp_back(const float* pooled, const float* mask, const flo
                                int C, int H, int W, float* refined, dasac_stream_t stream) {
   DASAC_REQUIRE(pooled && mask && theta_inv && refined && B > 0 && views_per_group > 0, "warp_back: bad arguments");
   DASAC_REQUIRE(C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "warp_back: bad shape");
-  const int items = (H + 1) / 2 * W;             // pairs of rows
+  const int items = (H + kWbRows - 1) / kWbRows * W;      // groups of kWbRows rows
   const int per = stream_grid(items, kHB, (kNumCu * 16 + B - 1) / B);
   hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
                      W, refined, per, items, fast_div(W));
