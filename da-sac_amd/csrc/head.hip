@@ -797,7 +797,8 @@ struct Sample {
   int o00, o01, o10, o11;     // flat offsets (clamped)
   float w00, w01, w10, w11;   // weights, 0 when the corner is out of bounds
 };
-__device__ __forceinline__ Sample make_sample(const float* __restrict__ th, int oy, int ox, int H, int W) {
+__device__ __forceinline__ Sample make_sample_ex(const float* __restrict__ th, int oy, int ox, int H, int W, int& cx0o, int& cx1o,
+                                                 int& cy0o, int& cy1o) {
   const float xb = (2.f * (float)ox + 1.f) / (float)W - 1.f;
   const float yb = (2.f * (float)oy + 1.f) / (float)H - 1.f;
   const float gx = th[0] * xb + th[1] * yb + th[2];
@@ -821,7 +822,43 @@ __device__ __forceinline__ Sample make_sample(const float* __restrict__ th, int 
   s.w01 = (vx1 && vy0) ? wx1 * wy0 : 0.f;
   s.w10 = (vx0 && vy1) ? wx0 * wy1 : 0.f;
   s.w11 = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+  cx0o = cx0; cx1o = cx1; cy0o = cy0; cy1o = cy1;
   return s;
+}
+__device__ __forceinline__ Sample make_sample(const float* __restrict__ th, int oy, int ox, int H, int W) {
+  int a, b, c, d;
+  return make_sample_ex(th, oy, ox, H, W, a, b, c, d);
+}
+// The same sample with its four taps as TWO 8-byte gathers (round 5: the warp kernels are bound by the number of gather / store
+// instructions their CU's address unit processes -- 130 us of gathers + 91 us of stores = warp_back's 220 -- not by bytes).  The
+// two taps of a source row sit in columns {pb, pb + 1}, pb = min(cx0, W - 2): one dwordx2 at (row, pb) holds both, and a select
+// per tap puts each into place (clamped columns included: cx0, cx1 are always pb or pb + 1).  W >= 2.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+struct SampleP {
+  unsigned a_top, a_bot;      // byte offsets of the two pairs
+  bool hi0, hi1;              // tap column == pb + 1
+  float w00, w01, w10, w11;
+};
+__device__ __forceinline__ SampleP make_sample_pair(const float* __restrict__ th, int oy, int ox, int H, int W) {
+  int cx0, cx1, cy0, cy1;
+  const Sample s = make_sample_ex(th, oy, ox, H, W, cx0, cx1, cy0, cy1);
+  const int pb = min(cx0, W - 2);
+  SampleP p;
+  p.a_top = (unsigned)(cy0 * W + pb) * 4u;
+  p.a_bot = (unsigned)(cy1 * W + pb) * 4u;
+  p.hi0 = cx0 != pb;
+  p.hi1 = cx1 != pb;
+  p.w00 = s.w00; p.w01 = s.w01; p.w10 = s.w10; p.w11 = s.w11;
+  return p;
+}
+__device__ __forceinline__ f32x2u ld_pair(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const f32x2u*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// pl[o00]*w00 + pl[o01]*w01 + pl[o10]*w10 + pl[o11]*w11 from the two pairs, same order as take()
+__device__ __forceinline__ float blend_pairs(const f32x2u t, const f32x2u b, const SampleP& p) {
+  const float v00 = p.hi0 ? t[1] : t[0], v01 = p.hi1 ? t[1] : t[0];
+  const float v10 = p.hi0 ? b[1] : b[0], v11 = p.hi1 ? b[1] : b[0];
+  return v00 * p.w00 + v01 * p.w01 + v10 * p.w10 + v11 * p.w11;
 }
 __device__ __forceinline__ float take(const float* __restrict__ pl, const Sample& s) {
   return pl[s.o00] * s.w00 + pl[s.o01] * s.w01 + pl[s.o10] * s.w10 + pl[s.o11] * s.w11;
@@ -955,7 +992,7 @@ __device__ __forceinline__ void warp_pool_rows(const float* __restrict__ probs_n
                                                const float* __restrict__ theta_inv_n, int H, int W, int HW, float tol,
                                                float* __restrict__ aligned_n, float* __restrict__ pooled_n,
                                                float* __restrict__ mask_n, int oy, int ox) {
-  Sample s[R][TT];
+  Sample s[R][TT];                              // (8-byte pair gathers as in warp_back: 280 against 225 us here -- four dword gathers stay)
   float cov[R][TT];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -1032,7 +1069,9 @@ __global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ p
 // 204 / 215 / 205 us against 214 / 232 / 215 at 8 x 19 x 769^2.  L2 fills per launch (FETCH_SIZE x 2): 687 MB with one row, 568
 // with two, 503 with four (kWbRows) against 360 MB for one pass per view; kernel time 217 / 208 / 202 us.  Knock-outs: without
 // its stores 130 us, without its gathers 91 us, without both 32 us -- 130 + 91 = the kernel: loads and stores do not overlap,
-// the launch moves ~880 MB through the L2-fabric path at ~4.4 TB/s whichever way the bytes go.
+// what adds up is the number of gather / store instructions the CU's address unit works through.  Hence (late in the round) the
+// four taps as two 8-byte pair gathers (SampleP) and the next class's gathers issued in front of this class's stores: 219 -> 192
+// us, same box.  (The same pairs in warp_pool_avg: 225 -> 281 us -- kept there as four dword gathers.)
 // (Measured and rejected on the way: four horizontally adjacent pixels per thread with dwordx4 stores 364 us -- gathers whose
 // lanes sit 16 bytes apart; an XCD-aware chunk order (XCD x walks the x-th eighth of every pass, so that vertical neighbours
 // share an L2) 224 against 208 us here and 445 against 311 us for warp_pool: what these kernels need is the linear pixel
@@ -1048,47 +1087,60 @@ template <int R>
 __device__ __forceinline__ void warp_back_rows(const float* __restrict__ pooled_n, const float* __restrict__ mask_n,
                                                const float* __restrict__ th, float* __restrict__ refined_b, int C, int H, int W,
                                                int HW, int oy, int ox) {
-  Sample s[R];
+  SampleP s[R];
   float mv[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    s[r] = make_sample(th, oy + r, ox, H, W);
-    mv[r] = take_off(mask_n, s[r]);
+    s[r] = make_sample_pair(th, oy + r, ox, H, W);
+    mv[r] = blend_pairs(ld_pair(mask_n, s[r].a_top), ld_pair(mask_n, s[r].a_bot), s[r]);
   }
   const unsigned o0 = (unsigned)(oy * W + ox) * 4u, pitch = (unsigned)W * 4u;
-  auto batch = [&](int c, auto nc_tag) {
-    constexpr int NC = decltype(nc_tag)::value;
-    float t[NC][R][4];
+  // One class = R * 2 pair gathers and R stores.  vmcnt retires a wave's loads and stores in issue order, so a class whose
+  // gathers are issued AFTER the previous class's stores waits for those stores to drain: two register sets, the next class's
+  // gathers go out before this class's stores (208 against 221 us, same box).
+  auto load = [&](f32x2u (&t)[R][2], int c) {
+    const float* pl = pooled_n + (size_t)c * HW;
 #pragma unroll
-    for (int u = 0; u < NC; ++u) {
-      const float* pl = pooled_n + (size_t)(c + u) * HW;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < R; ++r) {
 #ifdef DASAC_EXP_WB_NOLOAD
-        t[u][r][0] = s[r].w00 + c; t[u][r][1] = s[r].w01 + u; t[u][r][2] = s[r].w10 - c; t[u][r][3] = s[r].w11 * 2.f;
+      t[r][0] = f32x2u{s[r].w00 + c, s[r].w01};
+      t[r][1] = f32x2u{s[r].w10 - c, s[r].w11 * 2.f};
 #else
-        t[u][r][0] = ld_off(pl, (unsigned)s[r].o00 * 4u); t[u][r][1] = ld_off(pl, (unsigned)s[r].o01 * 4u);
-        t[u][r][2] = ld_off(pl, (unsigned)s[r].o10 * 4u); t[u][r][3] = ld_off(pl, (unsigned)s[r].o11 * 4u);
+      t[r][0] = ld_pair(pl, s[r].a_top);
+      t[r][1] = ld_pair(pl, s[r].a_bot);
 #endif
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NC; ++u) {
-      float* out = refined_b + (size_t)(c + u) * HW;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float a = t[u][r][0] * s[r].w00 + t[u][r][1] * s[r].w01 + t[u][r][2] * s[r].w10 + t[u][r][3] * s[r].w11;
-#ifdef DASAC_EXP_WB_NOSTORE
-        if (a == 1.2345e-30f)
-#endif
-        *at_off(out, o0 + (unsigned)r * pitch) = a * mv[r];
-      }
     }
   };
-  constexpr int NCB = R >= 4 ? 1 : 2;           // 16 taps in flight either way
+  auto store = [&](const f32x2u (&t)[R][2], int c) {
+    float* out = refined_b + (size_t)c * HW;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float a = blend_pairs(t[r][0], t[r][1], s[r]);
+#ifdef DASAC_EXP_WB_NOSTORE
+      if (a == 1.2345e-30f)
+#endif
+      *at_off(out, o0 + (unsigned)r * pitch) = a * mv[r];
+    }
+  };
+  f32x2u ta[R][2], tb[R][2];
+  load(ta, 0);
   int c = 0;
-  for (; c + NCB <= C; c += NCB) batch(c, std::integral_constant<int, NCB>{});
-  for (; c < C; ++c) batch(c, std::integral_constant<int, 1>{});
+#ifdef DASAC_EXP_WB_NOPIPE
+  for (; c < C; ++c) {
+    store(ta, c);
+    if (c + 1 < C) load(ta, c + 1);
+  }
+#else
+  for (; c + 2 <= C; c += 2) {
+    load(tb, c + 1);
+    __builtin_amdgcn_sched_barrier(0);          // the gathers of class c + 1 stay in front of the stores of class c
+    store(ta, c);
+    if (c + 2 < C) load(ta, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    store(tb, c + 1);
+  }
+  if (c < C) store(ta, c);
+#endif
 }
 __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ pooled, const float* __restrict__ mask,
                                                  const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
@@ -1390,7 +1442,7 @@ extern "C" int dasac_warp_pool(const float* probs, const float* theta, const flo
 extern "C" int dasac_warp_back(const float* pooled, const float* mask, const float* theta_inv, int B, int views_per_group,
                                int C, int H, int W, float* refined, dasac_stream_t stream) {
   DASAC_REQUIRE(pooled && mask && theta_inv && refined && B > 0 && views_per_group > 0, "warp_back: bad arguments");
-  DASAC_REQUIRE(C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "warp_back: bad shape");
+  DASAC_REQUIRE(C > 0 && H > 0 && W >= 2 && (int64_t)H * W < (1ll << 30), "warp_back: bad shape (two columns at least)");
   const int items = (H + kWbRows - 1) / kWbRows * W;      // groups of kWbRows rows
   const int per = stream_grid(items, kHB, (kNumCu * 16 + B - 1) / B);
   hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
