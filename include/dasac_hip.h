@@ -217,7 +217,8 @@ int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, int OH, int 
  *     (mode 1, :218-236): probs [N*T,C,H,W] -> pooled [N,C,H,W], mask [N,H,W]; `aligned`
  *     (optional) = teacher_aligned diagnostic [N*T,C,H,W].  theta == theta_inv == NULL: `probs` are
  *     views that are already aligned and coverage-weighted (the pooling functions on their own).
- * dasac_warp_back         sac.py:309-311: refined[b] = warp(pooled[b/views_per_group]) * warp(mask)
+ * dasac_warp_back         sac.py:309-311: refined[b] = warp(pooled[b/views_per_group]) * warp(mask); W >= 2 (DASAC_EINVAL
+ *     otherwise: the kernel fetches the two taps of a source row as one 8-byte pair)
  * dasac_class_state       sac.py:104-117 running prior update (if update) and the derived
  *     vectors disc = 1-exp(-chi/beta) (:152), focal = (1-max(chi,0))^p (:120); any may be NULL.
  */
