@@ -75,24 +75,28 @@ def test_full_resolution_head_parity_eight_crops_four_views():
     assert c["dlogits_max_err_over_tensor_max"] <= 1e-4
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` without torch.distributed.run (what the driver runs for the scaling curve): two ranks, here
-    both on the single device of the box (DASAC_BENCH_RANKS_PER_GPU=2 -> gloo transport), tiny crops; exactly one JSON line
-    on stdout with n_gpus = 2 and the process group's world size."""
-    env = dict(os.environ, DASAC_BENCH_RANKS_PER_GPU="2")
+@pytest.mark.parametrize("ranks,size", [(2, 129), (8, 65)])
+def test_bench_launches_its_own_ranks(ranks, size):
+    """`python bench.py --gpus N` without torch.distributed.run (what the driver runs for the scaling curve): N ranks, here
+    all on the single device of the box (DASAC_BENCH_RANKS_PER_GPU=N -> gloo transport), tiny crops; exactly one JSON line
+    on stdout with n_gpus = N, the process group's world size and one `per_rank` entry per rank (N = 8: the driver's own
+    8-GPU command)."""
+    env = dict(os.environ, DASAC_BENCH_RANKS_PER_GPU=str(ranks))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "129",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--size", str(size),
            "--batch", "2", "--groups", "1", "--views", "2", "--profile-steps", "1"]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 2
+    assert line["n_gpus"] == ranks and line["value"] > 0 and line["steps"] == 2
     d = line["config"]["distributed"]
-    assert d["world_size"] == 2 and d["self_launched"] and d["wrapper"] == "overlapped" and d["ranks_per_gpu"] == 2
-    assert line["config"]["global_batch"] == 4
+    assert d["world_size"] == ranks and d["self_launched"] and d["wrapper"] == "overlapped" and d["ranks_per_gpu"] == ranks
+    assert sorted(e["rank"] for e in d["per_rank"]) == list(range(ranks))
+    assert all(e["ms_per_step"] > 0 for e in d["per_rank"])
+    assert line["config"]["global_batch"] == 2 * ranks
     assert "roofline" in line and line["kernels"]
 
 

@@ -1,7 +1,8 @@
 """dasac_hip.parallel.OverlappedDataParallel: the gradient all-reduce issued bucket by bucket from INSIDE the engine's
 backward pass (DistributedDataParallel's overlap, /root/reference/train.py:104,133,232).  Checked against (1) the bare
-module -- the flat-buffer gradient sink must not change a bit -- and (2) two ranks on the one GPU of the box (gloo
-transport) against a one-process emulation that averages the per-rank gradients by hand."""
+module -- the flat-buffer gradient sink must not change a bit -- and (2) 2, 4 and 8 ranks on the one GPU of the box (gloo
+transport; RCCL with a GPU per rank where the box has them) against a one-process emulation that averages the per-rank
+gradients by hand."""
 import os
 from types import SimpleNamespace as NS
 
@@ -28,12 +29,12 @@ def _build(seed=3):
     return cfg, net
 
 
-def _two_passes(step_net, src, tgt, lr_target):
+def _two_passes(step_net, src, tgt, lr_target, T=2):
     ls, _ = step_net(*src)
     for p in step_net.parameters():
         p.grad = None
     ls["loss_ce"].mean().backward()
-    lt, _ = step_net(tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4], use_teacher=True, update_teacher=True, T=2)
+    lt, _ = step_net(tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4], use_teacher=True, update_teacher=True, T=T)
     (lr_target * lt["self_ce"].mean()).backward()
     return float(ls["loss_ce"]), float(lt["self_ce"])
 
@@ -107,6 +108,12 @@ def test_wrapper_refuses_trainable_parameters_it_would_never_reduce():
         wrapped(*src)
 
 
+# per-rank target batch of the multi-rank cases: (groups, views).  world 2 keeps the small historical case; worlds 4 and 8 run
+# cfg-4's shape -- WHOLE groups per rank (N*L/world >= L: no SAC-specific collective, train.py:186-187), 2 groups x 4 views
+def _tgt_shape(world):
+    return (1, 2) if world == 2 else (2, 4)
+
+
 def _rank_main(rank, world, port, q, use_torch_ddp):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -129,8 +136,9 @@ def _rank_main(rank, world, port, q, use_torch_ddp):
         ddp = nn.parallel.DistributedDataParallel(net, device_ids=[dev])
     else:
         ddp = OverlappedDataParallel(net, device_ids=[dev], bucket_mb=8)
-    src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=50 + rank)
-    losses = _two_passes(ddp, src, tgt, cfg.LR_TARGET)
+    groups, views = _tgt_shape(world)
+    src, tgt = driver.synthetic_batches(2, groups, views, (33, 49), "cuda", seed=50 + rank)
+    losses = _two_passes(ddp, src, tgt, cfg.LR_TARGET, T=views)
     grads = {k: p.grad.detach().cpu().numpy() for k, p in net.backbone.named_parameters() if k in _PROBE}
     optim.step()
     torch.cuda.synchronize()
@@ -143,7 +151,7 @@ def _rank_main(rank, world, port, q, use_torch_ddp):
     dist.destroy_process_group()
 
 
-def _spawn(use_torch_ddp):
+def _spawn(use_torch_ddp, world=2):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -152,24 +160,29 @@ def _spawn(use_torch_ddp):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, use_torch_ddp)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, use_torch_ddp)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    got = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     return got
 
 
-def test_two_ranks_overlapped_reduction_equals_the_manual_mean_and_stock_ddp():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_overlapped_reduction_equals_the_manual_mean_and_stock_ddp(world):
+    """world 4 / 8: cfg-4's per-rank shape with all ranks on the box's one device (gloo) -- bucket
+    bookkeeping, 1/world scaling and the construction-time broadcast run with rank >= 2 before any 8-GPU box sees them."""
     import driver
-    got = _spawn(False)
-    # construction synchronised rank 1 to rank 0 (parameters, synced and exempt buffers); both ranks end up identical
-    assert got[0][5] == got[1][5]
-    for k in _PROBE:
-        assert (got[0][2][k] == got[1][2][k]).all(), k
-        assert (got[0][3][k] == got[1][3][k]).all(), k
+    got = _spawn(False, world)
+    # construction synchronised every rank to rank 0 (parameters, synced and exempt buffers); all ranks end up identical
+    for r in range(1, world):
+        assert got[0][5] == got[r][5]
+        assert got[0][4] == got[r][4]              # the same buckets, launches and early launches everywhere
+        for k in _PROBE:
+            assert (got[0][2][k] == got[r][2][k]).all(), (k, r)
+            assert (got[0][3][k] == got[r][3][k]).all(), (k, r)
     # every bucket was reduced in both backward passes, all but the last of each pass BEFORE the backward ended
     n_buckets, launched, early = got[0][4]
     assert n_buckets >= 4 and launched == 2 * n_buckets and early >= 2 * (n_buckets - 1)
@@ -177,17 +190,20 @@ def test_two_ranks_overlapped_reduction_equals_the_manual_mean_and_stock_ddp():
     cfg, net = _build(seed=3)
     start = {k: v.clone() for k, v in net.state_dict().items()}
     grads, losses = [], []
-    for rank in range(2):
+    groups, views = _tgt_shape(world)
+    for rank in range(world):
         net.load_state_dict(start)
-        src, tgt = driver.synthetic_batches(2, 1, 2, (33, 49), "cuda", seed=50 + rank)
-        losses.append(_two_passes(net, src, tgt, cfg.LR_TARGET))
+        src, tgt = driver.synthetic_batches(2, groups, views, (33, 49), "cuda", seed=50 + rank)
+        losses.append(_two_passes(net, src, tgt, cfg.LR_TARGET, T=views))
         grads.append({n: p.grad.clone() for n, p in net.backbone.named_parameters() if p.requires_grad})
-    for rank in range(2):
+    for rank in range(world):
         assert got[rank][1] == pytest.approx(losses[rank], rel=1e-5)
     for k in _PROBE:
-        ref = ((grads[0][k] + grads[1][k]) / 2).cpu()
+        ref = (sum(g[k].double() for g in grads) / world).float().cpu()
         out = torch.from_numpy(got[0][3][k])
         assert float((ref - out).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, k
+    if world != 2:
+        return
     # and the stock DistributedDataParallel wrapper over the same engine gives the same parameters after the step
     stock = _spawn(True)
     for k in _PROBE:
