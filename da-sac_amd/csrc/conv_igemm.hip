@@ -31,10 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBK = 16;            // K-step of the forward/dgrad kernel
 constexpr int kThreads = 256;      // 4 waves
 constexpr int kInvalid = 1 << 20;  // dh of a padded table row: never in bounds
-#ifndef DASAC_SK_PER_CU
-#define DASAC_SK_PER_CU 3                                // experiment builds: -DDASAC_SK_PER_CU=4 (128 registers, spills: see DESIGN 5a)
-#endif
-constexpr int kSkWorkersPerCu = DASAC_SK_PER_CU;         // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each)
+constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each; four spill: EXPERIMENTS.md)
 constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8: the grid of every stream-K launch
 
 #ifdef DASAC_TRACE_TILES
@@ -126,11 +123,21 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // and only instruction-scheduling luck had put them there.  put_mask_rows: the two 32-bit halves of a wave ballot over accumulator
 // register `rg` are the mask words of rows (rg&3) + 8*(rg>>2) (lanes 0-31) and 4 below (lanes 32-63) of a 32x32 MFMA tile: lane r
 // of `acc` collects row r.
+// Toolchain note: a compiler that has the builtin uses it; otherwise the intrinsic's overloaded name
+// `llvm.amdgcn.writelane.i32` is the one of LLVM 19+ (ROCm >= 6.3; this image: ROCm 7.2) -- older toolchains spell it
+// `llvm.amdgcn.writelane` and are not supported by this build ("toolchain").
+#if __has_builtin(__builtin_amdgcn_writelane)
+template <int LANE>
+__device__ __forceinline__ int writelane_c(int val, int old) {
+  return __builtin_amdgcn_writelane(val, LANE, old);
+}
+#else
 extern "C" __device__ int dasac_llvm_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 template <int LANE>
 __device__ __forceinline__ int writelane_c(int val, int old) {
   return dasac_llvm_writelane(val, LANE, old);
 }
+#endif
 __device__ __forceinline__ int put_mask_rows(int rg, unsigned long long ballot, int acc) {
   const int lo = (int)(unsigned)ballot, hi = (int)(unsigned)(ballot >> 32);
   switch (rg) {      // rg is the index of a fully unrolled loop: the switch folds to one case
@@ -604,11 +611,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
               if constexpr (RELU) v = fmaxf(v, 0.f);
               if (BITS != 2 && ep.mask) v = mk[i - I0][rg] > 0.f ? v : 0.f;
               if constexpr (BITS == 2) v = (mb4[e] & lane_bit) ? v : 0.f;
-#ifndef DASAC_EXP_NOSTORE
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, DASAC_VOFF(i, rg), DASAC_ROW(i, rg) * OutHWe * 4, 0);
-#else
-              if (v == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, DASAC_VOFF(i, rg), DASAC_ROW(i, rg) * OutHWe * 4, 0);
-#endif
               if constexpr (BITS == 1)      // lanes 0-31 hold row (rg&3) + 8*(rg>>2), lanes 32-63 the row 4 below it: two words per ballot
                 bitrows = put_mask_rows(rg, __builtin_amdgcn_ballot_w64(v > 0.f), bitrows);
             }
@@ -640,19 +643,8 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
 #undef DASAC_ROW
 #undef DASAC_VOFF
     };
-#ifdef DASAC_EXP_NOEPI
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" ::"v"(acc[i][j]));
-#endif
-      }
-#else
     if (m0 + BM <= g.M) epilogue(std::true_type{});
     else epilogue(std::false_type{});
-#endif
     } else {
       // ---- BITS == 3: raw convolution (+ bias) in front of a batch-statistics BatchNorm.  No residual / ReLU / mask here (they
       // follow the normalisation); instead the per-row sum and sum of squares of the stored values.  Row groups are the OUTER
@@ -1382,19 +1374,19 @@ static bool persistent_grid_fits() {
   return ok;
 }
 
-// workers of a persistent stream-K launch: 3 per CU on the CUs this process does not leave to overlapped collectives
-static int sk_workers() { return (kNumCu - reserved_cus()) * kSkWorkersPerCu; }
+// workers of a persistent stream-K launch: 3 per CU on the CUs this process does not leave to overlapped collectives.  `reserved` is
+// read ONCE per launch decision (reserved_cus()) and handed through: a concurrent dasac_set_reserved_cus must not make the
+// eligibility test, the schedule choice and the grid size of one launch disagree.
+static int sk_workers(int reserved) { return (kNumCu - reserved) * kSkWorkersPerCu; }
 
-static bool want_streamk(int tiles, int k_steps) {
-  static const int mode = getenv("DASAC_STREAMK") ? atoi(getenv("DASAC_STREAMK")) : 1;   // 0 off, 1 auto, 2 always
+static bool want_streamk(int tiles, int k_steps, int reserved) {
   if (!persistent_grid_fits()) return false;
-  if (mode == 0 || (long long)tiles * k_steps < sk_workers()) return false;             // every range gets >= 1 K-step
-  if (mode == 2) return true;
+  if ((long long)tiles * k_steps < sk_workers(reserved)) return false;                  // every range gets >= 1 K-step
   // measured: the persistent schedule (3 workers/CU, <=168 registers) wins on long contractions whose tile count
   // fills the last round of the plain launch badly; short-K 1x1 layers are better off with the plain kernel's
   // 4 blocks per CU (128 registers) even with a partly empty last round (85 vs 99 TFLOP/s at K = 256) -- unless
   // the launch would leave most of the chip idle (small batches: 296 tiles at B = 2, 148 at B = 1).
-  const int resident = (kNumCu - reserved_cus()) * 3;
+  const int resident = (kNumCu - reserved) * 3;
   const int rounds = (tiles + resident - 1) / resident;
   const double eff = (double)tiles / ((double)rounds * resident);
   return k_steps >= 64 ? eff < 0.93 : (k_steps >= 16 && eff < 0.6);
@@ -1406,14 +1398,15 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
                        const Epilogue& ep, int n_tiles, int schedule, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
   if ((long long)m_tiles * (n_tiles + kNumXcd) * (g.Kpad / BK) >= (1ll << 31)) return fail(DASAC_EINVAL, "conv_gemm: iteration space exceeds 2^31");
-  const bool sk_ok = BM == 128 && workspace && (long long)m_tiles * n_tiles * (g.Kpad / BK) >= sk_workers() && persistent_grid_fits();
-  if (sk_ok && (schedule == 2 || (schedule == 0 && want_streamk(m_tiles * n_tiles, g.Kpad / BK)))) {
+  const int reserved = reserved_cus();
+  const bool sk_ok = BM == 128 && workspace && (long long)m_tiles * n_tiles * (g.Kpad / BK) >= sk_workers(reserved) && persistent_grid_fits();
+  if (sk_ok && (schedule == 2 || (schedule == 0 && want_streamk(m_tiles * n_tiles, g.Kpad / BK, reserved)))) {
     const size_t part_bytes = (size_t)kSkWorkers * (BM * BN) * sizeof(float);
     const size_t need = part_bytes + (size_t)(kSkWorkers + 1) * sizeof(int);
     if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
     float* partial = reinterpret_cast<float*>(workspace);
     int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
-    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS>), dim3(sk_workers()), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
+    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS>), dim3(sk_workers(reserved)), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
                        ep, m_tiles, n_tiles, partial, flags);
     return DASAC_OK;
   }
@@ -1496,7 +1489,7 @@ extern "C" int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K) {
   const int Mpad = dasac_conv_mpad(M);
   if (pick_bm(Mpad) != 128) return 0;
   const int tiles = ((M + 127) / 128) * ((Nb * OH * OW + 127) / 128);
-  return want_streamk(tiles, (K + kBK - 1) / kBK) ? 1 : 0;
+  return want_streamk(tiles, (K + kBK - 1) / kBK, reserved_cus()) ? 1 : 0;
 }
 
 // Long-K convs whose tile count does not fill whole rounds of resident blocks are best issued as TWO launches:
@@ -1504,16 +1497,15 @@ extern "C" int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K) {
 // share their halo rows in L2: measured 0.13 GB instead of 1.0 GB of HBM reads on the layer3 3x3) and only the
 // remainder on the persistent stream-K schedule.  Returns the pixel count of the leading launch, 0 = do not split.
 extern "C" int dasac_conv_gemm_plan(int Nb, int OH, int OW, int M, int K) {
-  static const int mode = getenv("DASAC_HYBRID") ? atoi(getenv("DASAC_HYBRID")) : 1;
   const int Mpad = dasac_conv_mpad(M);
-  if (!mode || pick_bm(Mpad) != 128) return 0;
+  if (pick_bm(Mpad) != 128) return 0;
   const int m_tiles = (M + 127) / 128, n_tiles = (Nb * OH * OW + 127) / 128, k_steps = (K + kBK - 1) / kBK;
   const int tiles = m_tiles * n_tiles;
   const int slots = kNumCu * 4;                                  // resident blocks of the tile-per-block kernel
   // (Round 4, measured and rejected: extending this split to the short-K layers -- 16 <= K-steps < 64, many whole rounds plus a last
   // one filled below half -- moves 59 more launches per cfg-3 step to stream-K: one block per tile 248.5 -> 246.9 ms, stream-K
   // 28.9 -> 32.6 ms.  A remainder launch costs its ~25 us of ramp and hand-off whatever it saves of a thin last round.)
-  if (!want_streamk(tiles, k_steps)) return 0;
+  if (!want_streamk(tiles, k_steps, reserved_cus())) return 0;
   const int lead = (tiles / slots) * slots / m_tiles;            // pixel tiles of the leading whole rounds
   if (lead == 0 || lead >= n_tiles) return 0;
   return lead * 128;
@@ -1548,11 +1540,6 @@ static int conv_gemm_impl(bool x3, const float* x, const float* packed, const in
   DASAC_REQUIRE(!relu_bits_out || relu, "conv_gemm: relu_bits_out records the pattern of a ReLU epilogue");
   DASAC_REQUIRE(!(x3 && (mask_bits || relu_bits_out)), "conv_gemm_x3: bit masks are implemented for the fp32 kernel only");
   DASAC_REQUIRE(!stats || (!res && !relu), "conv_gemm_stats: the statistics epilogue stores the raw convolution (+ shift): no residual, no ReLU");
-  // plain 1x1 stride-1 convolution with a short contraction over the whole pixel range: the M-sweep kernel (bit-identical)
-  if (!x3 && !stats && !mask && schedule == 0 && K == Cx && stride == 1 && ostride == 1 && OH == H && OW == W && OutH == OH &&
-      OutW == OW && pix_begin == 0 && (pix_count <= 0 || pix_count == Nb * OH * OW) && (int64_t)Nb * OH * OW < (1ll << 31) &&
-      dasac_gemm1x1_msweep_ok(M, K))
-    return dasac_gemm1x1_msweep(x, packed, out, Nb, K, H * W, M, shift, res, mask_bits, relu_bits_out, relu, stream);
   GemmGeom g;
   const int Mpad = dasac_conv_mpad(M), Kloop = (K + kBK - 1) / kBK * kBK;   // table/pack are padded to 128 >= Kloop
   int rc = fill_geom(g, Nb, Cx, H, W, OH, OW, stride, M, Mpad, Kloop, OutH, OutW, ostride);
@@ -1678,10 +1665,8 @@ static int wgrad_splits(int Mpad, int Kpad, int Npix, int BM, int BNk = 128) {
   // 1x1 layers at 19 splits = 304 blocks for 768 slots; measured in round 4 (profiles/r4_wgrad_split_granularity.txt, cfg-2):
   // 1024 -> 512 -> 256 pixels: weight gradients 18.7 -> 16.3 -> 15.4 ms/step (90 -> 103 -> 109 TFLOP/s).  Large batches are
   // unaffected (the cap of 64 splits binds first).
-#ifndef DASAC_WG_MINPIX
-#define DASAC_WG_MINPIX 256
-#endif
-  int max_splits = (Npix + DASAC_WG_MINPIX - 1) / DASAC_WG_MINPIX;
+  constexpr int kMinPix = 256;
+  int max_splits = (Npix + kMinPix - 1) / kMinPix;
   // few tiles x many pixels (layer1 / stem: 2 tiles, 298k..1.2M pixels): more splits, or 128 blocks would face 768 slots
   const int cap = (tiles < 12 && Npix >= 200000) ? (slots + tiles - 1) / tiles : 64;   // measured: no gain at 97x97 resolution
   if (max_splits > cap) max_splits = cap;
@@ -1736,8 +1721,7 @@ static int conv_wgrad_impl(bool x3, const float* dz, const float* x, const int32
   switch (bm) {
     case 128: {
       // 1x1 stride-1 layers: both operands are plain [row][pixel] matrices -> four pixels per lane (conv_wgrad<..., QUAD>)
-      static const int quad_mode = getenv("DASAC_WGRAD_QUAD") ? atoi(getenv("DASAC_WGRAD_QUAD")) : 1;
-      const bool quad = quad_mode && fast && !x3 && K == Cx && stride == 1 && H == OH && W == OW && M % 128 == 0;   // one tap, no padding
+      const bool quad = fast && !x3 && K == Cx && stride == 1 && H == OH && W == OW && M % 128 == 0;   // one tap, no padding
       if (quad) {
         const int m_tiles = g.Mpad / 128, k_tiles = g.Kpad / 128;
         const int grid = (m_tiles * k_tiles * splits + kNumXcd - 1) / kNumXcd * kNumXcd;
@@ -1942,3 +1926,4 @@ extern "C" int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, i
   DASAC_CHECK_LAUNCH("wgrad_reduce_expanded");
   return DASAC_OK;
 }
+

@@ -109,12 +109,8 @@ __global__ __launch_bounds__(kHB, (SOFTMAX && NARROW) ? 4 : 1) void upsample_sof
         const float* pl = xb + (size_t)c * hw;
         float val[4];
         if (narrow) {
-#ifdef DASAC_EXP_UP_NOLOAD
-          const float t0 = sh + c, t1 = sw + c, t2 = t0 * 1.5f, b0 = t1 * 0.5f, b1 = t0 + t1, b2 = t0 - t1;
-#else
           const float t0 = ld_off(pl, a00), t1 = ld_off(pl, a01), t2 = ld_off(pl, a02);
           const float b0 = ld_off(pl, a10), b1 = ld_off(pl, a11), b2 = ld_off(pl, a12);
-#endif
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float ta = hi[e] ? t1 : t0, tb = hi[e] ? t2 : t1;
@@ -172,11 +168,7 @@ __global__ __launch_bounds__(kHB, (SOFTMAX && NARROW) ? 4 : 1) void upsample_sof
 #pragma unroll
         for (int c = 0; c < CT; ++c)
           if (c < C) {
-#ifdef DASAC_EXP_UP_NOEXP
-            v[e][c] = v[e][c] - mx[e];
-#else
             v[e][c] = expf(v[e][c] - mx[e]);
-#endif
             den += v[e][c];
           }
         inv[e] = 1.f / den;
@@ -192,11 +184,7 @@ __global__ __launch_bounds__(kHB, (SOFTMAX && NARROW) ? 4 : 1) void upsample_sof
             if (e < nx) acc[c] += pr[e];
             if (ign[e]) pr[e] = 0.f;
           }
-#ifdef DASAC_EXP_UP_NOSTORE
-          if (probs && pr[0] == 1.2345e-30f) {
-#else
           if (probs) {
-#endif
             float* o = at_off(probs + obase + (size_t)c * HW, ooff);
             if (nx == 4) {
               *reinterpret_cast<f32x4u*>(o) = f32x4u{pr[0], pr[1], pr[2], pr[3]};
@@ -748,11 +736,7 @@ __global__ __launch_bounds__(kCW, 2) void ce_bwd_rows_wave(const float* __restri
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-#ifdef DASAC_EXP_CE_NOEXP
-          v[c][e] = v[c][e] - mx[e];
-#else
           v[c][e] = expf(v[c][e] - mx[e]);
-#endif
           den[e] += v[c][e];
         }
       float k[4], gw[4];
@@ -770,15 +754,9 @@ __global__ __launch_bounds__(kCW, 2) void ce_bwd_rows_wave(const float* __restri
         for (int e = 0; e < 4; ++e) wr[c * pitch + e] = k[e] * v[c][e] - ((c == lb[e]) ? gw[e] : 0.f);
     }
     __builtin_amdgcn_sched_barrier(0);                    // not earlier: the next row reuses this row's 76 registers
-#ifndef DASAC_EXP_CE_NOLOAD
     if (oy + 1 < y1) load_row(oy + 1);                    // in flight while this row is reduced
-#endif
     __syncthreads();
-#ifdef DASAC_EXP_CE_NOP2
-    if (red && sw == 123.f) {
-#else
     if (red) {
-#endif
 #pragma unroll 1
       for (int c = g0; c < CT; c += groups) {
         const char* row = reinterpret_cast<const char*>(s_d) + (unsigned)c * row_bytes;
@@ -979,10 +957,7 @@ __global__ __launch_bounds__(kHB) void warp_pool(const float* __restrict__ probs
 // no 64-bit per-lane address arithmetic in front of the 16 gathers and 4 stores of a class: 2054 instead of 2672 VALU instructions
 // per pixel, 325 -> 235 us at 2 x 4 x 19 x 769^2 (same box, tools/head_exp.py).  DASAC_WP_ROWS vertically adjacent pixels per
 // thread (the row below shares a source row: fewer L2 fills, as in warp_back): 2 rows need 256 VGPRs and run 566 us -- one row.
-#ifndef DASAC_WP_ROWS
-#define DASAC_WP_ROWS 1
-#endif
-constexpr int kWpRows = DASAC_WP_ROWS;
+constexpr int kWpRows = 1;
 __device__ __forceinline__ float take_off(const float* __restrict__ pl, const Sample& s) {
   return ld_off(pl, (unsigned)s.o00 * 4u) * s.w00 + ld_off(pl, (unsigned)s.o01 * 4u) * s.w01 + ld_off(pl, (unsigned)s.o10 * 4u) * s.w10 +
          ld_off(pl, (unsigned)s.o11 * 4u) * s.w11;
@@ -1076,10 +1051,7 @@ __global__ __launch_bounds__(kHB) void warp_pool_avg(const float* __restrict__ p
 // lanes sit 16 bytes apart; an XCD-aware chunk order (XCD x walks the x-th eighth of every pass, so that vertical neighbours
 // share an L2) 224 against 208 us here and 445 against 311 us for warp_pool: what these kernels need is the linear pixel
 // order's sequential DRAM streams, not fewer L2 fills.)
-#ifndef DASAC_WB_ROWS
-#define DASAC_WB_ROWS 4
-#endif
-constexpr int kWbRows = DASAC_WB_ROWS;       // vertically adjacent output pixels per thread
+constexpr int kWbRows = 4;       // vertically adjacent output pixels per thread
 // R rows of one output column: R sample descriptors, then the classes NC at a time with all NC * R * 4 taps issued before the
 // first is used (R, NC compile-time: as run-time predicates the compiler sinks the lower rows' taps under their test and waits
 // for four loads at a time).
@@ -1102,13 +1074,8 @@ __device__ __forceinline__ void warp_back_rows(const float* __restrict__ pooled_
     const float* pl = pooled_n + (size_t)c * HW;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-#ifdef DASAC_EXP_WB_NOLOAD
-      t[r][0] = f32x2u{s[r].w00 + c, s[r].w01};
-      t[r][1] = f32x2u{s[r].w10 - c, s[r].w11 * 2.f};
-#else
       t[r][0] = ld_pair(pl, s[r].a_top);
       t[r][1] = ld_pair(pl, s[r].a_bot);
-#endif
     }
   };
   auto store = [&](const f32x2u (&t)[R][2], int c) {
@@ -1116,21 +1083,12 @@ __device__ __forceinline__ void warp_back_rows(const float* __restrict__ pooled_
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const float a = blend_pairs(t[r][0], t[r][1], s[r]);
-#ifdef DASAC_EXP_WB_NOSTORE
-      if (a == 1.2345e-30f)
-#endif
       *at_off(out, o0 + (unsigned)r * pitch) = a * mv[r];
     }
   };
   f32x2u ta[R][2], tb[R][2];
   load(ta, 0);
   int c = 0;
-#ifdef DASAC_EXP_WB_NOPIPE
-  for (; c < C; ++c) {
-    store(ta, c);
-    if (c + 1 < C) load(ta, c + 1);
-  }
-#else
   for (; c + 2 <= C; c += 2) {
     load(tb, c + 1);
     __builtin_amdgcn_sched_barrier(0);          // the gathers of class c + 1 stay in front of the stores of class c
@@ -1140,7 +1098,6 @@ __device__ __forceinline__ void warp_back_rows(const float* __restrict__ pooled_
     store(tb, c + 1);
   }
   if (c < C) store(ta, c);
-#endif
 }
 __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ pooled, const float* __restrict__ mask,
                                                  const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
@@ -1159,6 +1116,23 @@ __global__ __launch_bounds__(kHB) void warp_back(const float* __restrict__ poole
     } else {                                    // the last rows of a height that is no multiple of kWbRows
       for (int y = oy; y < H; ++y) warp_back_rows<1>(pooled_n, mask_n, theta_inv + b * 6, refined_b, C, H, W, HW, y, ox);
     }
+  }
+}
+
+// W == 1: no pair of columns exists for the 8-byte gathers above -- four scalar taps per sample (make_sample / take, the same
+// products in the same order), one thread per output pixel.  Any size grid_sample accepts is accepted here too.
+__global__ __launch_bounds__(kHB) void warp_back_scalar(const float* __restrict__ pooled, const float* __restrict__ mask,
+                                                        const float* __restrict__ theta_inv, int group_div, int C, int H, int W,
+                                                        float* __restrict__ refined, int blocks_per_image) {
+  const int b = blockIdx.x / blocks_per_image, chunk = blockIdx.x % blocks_per_image;
+  const int n = b / group_div;
+  const int HW = H * W;
+  const float* pooled_n = pooled + (size_t)n * C * HW;
+  float* refined_b = refined + (size_t)b * C * HW;
+  for (int p = chunk * kHB + threadIdx.x; p < HW; p += blocks_per_image * kHB) {
+    const Sample s = make_sample(theta_inv + b * 6, p / W, p % W, H, W);
+    const float mv = take(mask + (size_t)n * HW, s);
+    for (int c = 0; c < C; ++c) refined_b[(size_t)c * HW + p] = take(pooled_n + (size_t)c * HW, s) * mv;
   }
 }
 
@@ -1376,10 +1350,9 @@ extern "C" int dasac_ce_loss_bwd_low(const float* logits_up, const int64_t* labe
     }
     // rows per block: ONE round of blocks that nearly fills the chip (two 224-register waves per SIMD = 8 blocks per CU); all
     // blocks do the same work, so a second, partly filled round would cost a whole round's time
-    static const int rows_env = getenv("DASAC_CE_ROWS") ? atoi(getenv("DASAC_CE_ROWS")) : 0;      // experiments only
     const int slots = (kNumCu - reserved_cus()) * 8;
     const int chunks_max = std::max(1, slots / std::max(1, B * wseg));
-    const int rows = rows_env > 0 ? rows_env : std::max(4, (H + chunks_max - 1) / chunks_max);
+    const int rows = std::max(4, (H + chunks_max - 1) / chunks_max);
     const int n_chunks = (H + rows - 1) / rows;
     const int wpitch = ce_lds_index(wspan - 1) + 2;
     if (wspan <= 256 && taps <= 24 && (int64_t)B * n_chunks * wseg < (1ll << 31) && (size_t)C * wpitch * sizeof(float) <= 60 * 1024) {
@@ -1442,7 +1415,14 @@ extern "C" int dasac_warp_pool(const float* probs, const float* theta, const flo
 extern "C" int dasac_warp_back(const float* pooled, const float* mask, const float* theta_inv, int B, int views_per_group,
                                int C, int H, int W, float* refined, dasac_stream_t stream) {
   DASAC_REQUIRE(pooled && mask && theta_inv && refined && B > 0 && views_per_group > 0, "warp_back: bad arguments");
-  DASAC_REQUIRE(C > 0 && H > 0 && W >= 2 && (int64_t)H * W < (1ll << 30), "warp_back: bad shape (two columns at least)");
+  DASAC_REQUIRE(C > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "warp_back: bad shape");
+  if (W < 2) {          // the pair gathers need two columns: scalar taps for one-column maps
+    const int per1 = stream_grid((int64_t)H * W, kHB, (kNumCu * 16 + B - 1) / B);
+    hipLaunchKernelGGL(warp_back_scalar, dim3(per1 * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C,
+                       H, W, refined, per1);
+    DASAC_CHECK_LAUNCH("warp_back");
+    return DASAC_OK;
+  }
   const int items = (H + kWbRows - 1) / kWbRows * W;      // groups of kWbRows rows
   const int per = stream_grid(items, kHB, (kNumCu * 16 + B - 1) / B);
   hipLaunchKernelGGL(warp_back, dim3(per * B), dim3(kHB), 0, as_stream(stream), pooled, mask, theta_inv, views_per_group, C, H,
@@ -1460,3 +1440,4 @@ extern "C" int dasac_class_state(float* running_conf, const double* class_sums, 
   DASAC_CHECK_LAUNCH("class_state");
   return DASAC_OK;
 }
+

@@ -25,8 +25,6 @@ PROTOTYPES = {
     "dasac_relu_bits_words": (_sz, [_i, _l]),
     "dasac_conv_gemm_bits_ok": (_i, [_i, _i]),
     "dasac_conv_gemm": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
-    "dasac_gemm1x1_msweep_ok": (_i, [_i, _i]),
-    "dasac_gemm1x1_msweep": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "dasac_conv_gemm_x3": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "dasac_conv_pack_x3": (_i, [_p, _i, _i, _p, _p]),
     "dasac_conv_gemm_workspace": (_sz, []),
@@ -130,9 +128,11 @@ EXPECTED_CUS, EXPECTED_ARCH = 256, "gfx950"       # csrc/common.hpp: kNumCu / kN
 
 
 def check_device(index):
-    """Fails loudly when the device is not what the kernels were tuned and compiled for: a full MI355X (gfx950, 64-wide
-    waves, 256 CUs in 8 XCDs).  A partitioned (CPX / fewer-CU) device would run with mistuned grids and a refused stream-K
-    schedule; DASAC_ALLOW_OTHER_DEVICE=1 turns the error into a warning for experiments."""
+    """Fails loudly when the device cannot run the library at all -- anything but gfx950 with 64-wide waves: the code objects
+    are compiled for that ISA only.  A gfx950 device with another CU count (a CPX / fewer-CU partition of an MI355X) RUNS every
+    kernel correctly: grids and tile runs are merely sized for 256 CUs in 8 XCDs, and the one schedule that depends on the CU
+    count, the persistent stream-K grid, refuses itself on the device side (`persistent_grid_fits`) and falls back to one
+    block per tile.  That case is a warning, once per device."""
     if index in _checked_devices:
         if isinstance(_checked_devices[index], DasacError):
             raise _checked_devices[index]
@@ -142,13 +142,17 @@ def check_device(index):
     with torch.cuda.device(index):
         check(lib.dasac_device_info(C.byref(cus), C.byref(wave), arch, 64), "dasac_device_info")
     info = (cus.value, wave.value, arch.value.decode().split(":")[0])
-    if info != (EXPECTED_CUS, 64, EXPECTED_ARCH):
-        msg = "libdasac_hip.so is built and tuned for {} with {} CUs and 64-wide waves; cuda:{} reports {} with {} CUs, wave {}".format(
-            EXPECTED_ARCH, EXPECTED_CUS, index, info[2], info[0], info[1])
+    if info[1:] != (64, EXPECTED_ARCH):
+        msg = "libdasac_hip.so is compiled for {} (64-wide waves) only; cuda:{} reports {}, wave {}".format(
+            EXPECTED_ARCH, index, info[2], info[1])
         if os.environ.get("DASAC_ALLOW_OTHER_DEVICE", "0") != "1":
-            raise DasacError(msg + " (set DASAC_ALLOW_OTHER_DEVICE=1 to run anyway)")
+            raise DasacError(msg + " (set DASAC_ALLOW_OTHER_DEVICE=1 to try anyway)")
         import warnings
         warnings.warn(msg)
+    elif info[0] != EXPECTED_CUS:
+        import warnings
+        warnings.warn("libdasac_hip.so sizes its grids for {} CUs; cuda:{} reports {} (partitioned device?): results are unaffected, "
+                      "the persistent stream-K schedule is off and launch shapes are not tuned".format(EXPECTED_CUS, index, info[0]))
     _checked_devices[index] = info
     return info
 

@@ -243,10 +243,6 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     if schedule is not None:
         launch("conv_gemm<stream-K>" if schedule == 2 else "conv_gemm<tile-per-block>", 0, 0, int(schedule))
         return out
-    if (stats is None and mask is None and fn is lib.dasac_conv_gemm and K == Cx and stride == 1 and ostride == 1 and (OH, OW) == (H, W)
-            and lib.dasac_gemm1x1_msweep_ok(M, K)):
-        launch("gemm1x1_msweep", 0, 0, 0)       # dasac_conv_gemm routes this call to the M-sweep kernel (same arguments, same bits)
-        return out
     lead = lib.dasac_conv_gemm_plan(Nb, OH, OW, M, K)
     if lead > 0:        # whole rounds one block per tile (lockstep over K: halo rows shared in L2), the rest stream-K
         launch("conv_gemm<tile-per-block>", 0, lead, 1)
@@ -254,23 +250,6 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     else:
         sk = PROFILE.on and lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K)
         launch("conv_gemm<stream-K>" if sk else "conv_gemm<tile-per-block>", 0, 0, 0)
-    return out
-
-
-def gemm1x1_msweep(x, packed, out, shift=None, res=None, mask=None, relu=False, bits_out=None):
-    """The M-sweep kernel called directly (dasac_gemm1x1_msweep; dasac_conv_gemm routes to it only with DASAC_MSWEEP=1): a 1x1 stride-1
-    convolution x [N,K,H,W] -> out [N,M,H,W] with K in {64,128,256}, M % 256 == 0; mask: a ReluBits of out's shape; bits_out as in conv_gemm."""
-    lib = L.load()
-    L.require_gpu(x, packed, out)
-    Nb, K, H, W = x.shape
-    M = out.shape[1]
-    assert out.shape == (Nb, M, H, W) and x.is_contiguous() and out.is_contiguous()
-    assert mask is None or isinstance(mask, ReluBits)
-    with PROFILE.span("gemm1x1_msweep", 2.0 * Nb * H * W * M * K, (M, K, Nb * H * W, 1, 1, res is not None, mask is not None),
-                      4.0 * (x.numel() + packed.numel() + out.numel() * (1 + (res is not None)))):
-        L.check(lib.dasac_gemm1x1_msweep(x.data_ptr(), packed.data_ptr(), out.data_ptr(), Nb, K, H * W, M, L.ptr(shift), L.ptr(res),
-                                         0 if mask is None else mask.words.data_ptr(), 0 if bits_out is None else bits_out.words.data_ptr(),
-                                         int(relu), L.stream_ptr()), "dasac_gemm1x1_msweep")
     return out
 
 

@@ -210,8 +210,13 @@ class OverlappedDataParallel(nn.Module):
         # CUs left to the collective's kernels, which run beside the backward GEMMs: the persistent stream-K grid gives every worker
         # the same matrix work, so a CU that also hosts RCCL workgroups finishes last.  8 by default under world > 1
         # (DASAC_SK_RESERVE_CUS overrides, 0 = none); a single rank keeps the whole chip.
+        # The setting is process-global in the library (one chip, one set of CUs): every launch of this process shrinks its
+        # stream-K grid while a wrapper with world > 1 is alive -- a different (tile, K-range) partition, i.e. a different
+        # summation order than a single-rank run (results agree to fp32 rounding, not bit for bit).  The previous value comes
+        # back when the wrapper is closed or collected.
+        self._prev_reserved = None
         if self._world() > 1 and "DASAC_SK_RESERVE_CUS" not in os.environ:
-            L.load().dasac_set_reserved_cus(8)
+            self._prev_reserved = L.load().dasac_set_reserved_cus(8)
         self._sinks = []
         for net in _trainable_backbones(module):
             sink = GradSink(process_group, int(bucket_mb) << 20, reduce_single_rank)
@@ -224,6 +229,19 @@ class OverlappedDataParallel(nn.Module):
 
     def _world(self):
         return dist.get_world_size(self.process_group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def close(self):
+        """Gives the reserved CUs back (idempotent).  Called by __del__; call it yourself when the wrapper is dropped while the
+        process keeps computing with the bare module."""
+        prev, self._prev_reserved = getattr(self, "_prev_reserved", None), None
+        if prev is not None:
+            try:
+                L.load().dasac_set_reserved_cus(prev)
+            except Exception:      # interpreter shutdown: the library may be gone
+                pass
+
+    def __del__(self):
+        self.close()
 
     @torch.no_grad()
     def _broadcast(self, tensors):

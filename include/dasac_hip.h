@@ -120,17 +120,6 @@ int dasac_conv_gemm(const float* x, const float* packed, const int32_t* table, f
                     const uint32_t* mask_bits, uint32_t* relu_bits_out,
                     int relu, int pix_begin, int pix_count, int schedule,
                     void* workspace, size_t ws_bytes, dasac_stream_t stream);
-/* M-sweep GEMM for the 1x1 stride-1 convolutions with K = 64 / 128 / 256 input channels and M % 256 == 0 output channels
- * (deeplabv2.py:70-71 conv3 + bn3 + residual + ReLU of every bottleneck; the data gradient of conv1, :59): one persistent
- * workgroup per CU keeps a 64-pixel activation tile [K x 64] in LDS and sweeps all M rows over it, the packed weights stream
- * from L2 straight into MFMA operand registers, the two waves of a SIMD alternate K loop and epilogue.  x [Nb,K,HW] ->
- * out [Nb,M,HW]; `packed`, shift / res / mask_bits / relu_bits_out / relu exactly as in dasac_conv_gemm, and the result is
- * bit-identical to it.  dasac_conv_gemm (schedule 0) routes eligible calls here itself when dasac_gemm1x1_msweep_ok(M, K)
- * (DASAC_MSWEEP=0 in the environment turns that off); no workspace. */
-int dasac_gemm1x1_msweep_ok(int M, int K);
-int dasac_gemm1x1_msweep(const float* x, const float* packed, float* out, int Nb, int K, int HW, int M,
-                         const float* shift, const float* res, const uint32_t* mask_bits, uint32_t* relu_bits_out,
-                         int relu, dasac_stream_t stream);
 /* Split-bf16 ("bf16x3") variant of the same contraction: every fp32 operand x is split into
  * head = bf16(x) and tail = bf16(x - head) and x*y is evaluated as xh*yh + xh*yl + xl*yh on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error of a product <= ~2^-15, typically
@@ -217,8 +206,8 @@ int dasac_conv_wgrad_finish_expanded(const void* workspace, int Nb, int OH, int 
  *     (mode 1, :218-236): probs [N*T,C,H,W] -> pooled [N,C,H,W], mask [N,H,W]; `aligned`
  *     (optional) = teacher_aligned diagnostic [N*T,C,H,W].  theta == theta_inv == NULL: `probs` are
  *     views that are already aligned and coverage-weighted (the pooling functions on their own).
- * dasac_warp_back         sac.py:309-311: refined[b] = warp(pooled[b/views_per_group]) * warp(mask); W >= 2 (DASAC_EINVAL
- *     otherwise: the kernel fetches the two taps of a source row as one 8-byte pair)
+ * dasac_warp_back         sac.py:309-311: refined[b] = warp(pooled[b/views_per_group]) * warp(mask); any H, W >= 1 (W >= 2
+ *     fetches the two taps of a source row as one 8-byte pair, one-column maps take four scalar taps: the same arithmetic)
  * dasac_class_state       sac.py:104-117 running prior update (if update) and the derived
  *     vectors disc = 1-exp(-chi/beta) (:152), focal = (1-max(chi,0))^p (:120); any may be NULL.
  */

@@ -350,77 +350,6 @@ def test_gemm_epilogue_channel_statistics(case):
     assert rel_err(dz, zc.grad) < 1e-4 and rel_err(dg, gamr.grad) < 1e-4 and rel_err(db, dyc.sum((0, 2, 3))) < 1e-5
 
 
-MSWEEP_CASES = [
-    # name, K (input channels), M (output channels), (N, H, W)
-    ("l3_conv3_ragged", 256, 1024, (2, 25, 33)),        # 1650 pixels: a ragged last tile, image boundaries inside pixel quads
-    ("tiny_planes", 256, 1024, (5, 7, 9)),              # 63-pixel planes: every 64-pixel tile spans two images
-    ("l2_conv3", 128, 512, (2, 31, 17)),                # one pass of 64-row blocks
-    ("l1_conv3", 64, 256, (1, 40, 40)),                 # 32-row blocks, half of the loader threads idle
-    ("m256_k256", 256, 256, (3, 19, 23)),               # M = 256: 32-row blocks, one pass
-    ("l3_conv3_cfg3", 256, 1024, (16, 97, 97)),         # the cfg-3 launch: 256 workgroups, runs that start / end inside a tile
-]
-
-
-@pytest.mark.parametrize("case", MSWEEP_CASES, ids=[c[0] for c in MSWEEP_CASES])
-def test_msweep_kernel_is_bit_identical_to_the_tile_per_block_kernel(case):
-    """dasac_gemm1x1_msweep (the persistent M-sweep kernel for 1x1 stride-1 layers with K <= 256; opt-in, DASAC_MSWEEP=1) against the
-    tile-per-block kernel forced with schedule=1: same per-accumulator MFMA sequence and the same epilogue expression, so outputs
-    -- and the recorded ReLU bit masks -- must be EQUAL, for every epilogue the network uses: shift only, shift + residual + ReLU
-    (conv3 forward, deeplabv2.py:70-71,91-97), the same recording its bit mask, residual + bit-mask (conv1 data gradient, :59)."""
-    from dasac_hip import ops
-    _, K, M, (N_, H, W) = case
-    g = torch.Generator().manual_seed(K + M + H)
-    spec = ops.ConvSpec(K, M, [(1, 1, 1, 0)], 1)
-    x = torch.randn(N_, K, H, W, generator=g).cuda()
-    w = (torch.randn(M, K, 1, 1, generator=g) / K ** 0.5).cuda()
-    shift = (torch.randn(M, generator=g) * 0.1).cuda()
-    res = torch.randn(N_, M, H, W, generator=g).cuda()
-    order = ops.gemm_order(spec, False)
-    table, packed = ops.conv_table(spec, H, W, False, x.device, order), ops.conv_pack(spec, [w], False, None, order=order)
-    npix = N_ * H * W
-    valid = torch.full(((npix + 31) // 32,), 0xFFFFFFFF, dtype=torch.int64, device="cuda")
-    if npix % 32:
-        valid[-1] = (1 << (npix % 32)) - 1
-
-    def run(schedule, shift_, res_, relu, want_bits=False, mask=None):
-        out = torch.full((N_, M, H, W), float("nan"), device="cuda")
-        bits = None
-        if want_bits:
-            bits = ops.ReluBits(N_, M, H, W, x.device)
-            bits.words.fill_(0x55555555)
-        if schedule is None:      # the M-sweep kernel itself (dasac_conv_gemm picks it only with DASAC_MSWEEP=1)
-            ops.gemm1x1_msweep(x, packed, out, shift_, res_, mask, relu, bits_out=bits)
-        else:
-            ops.conv_gemm(x, packed, table, out, (H, W), 1, M, K, 1, shift_, res_, mask, relu, bits_out=bits, schedule=schedule)
-        return out, bits
-
-    # against torch first (the reference arithmetic), then kernel against kernel
-    y_ms, _ = run(None, shift, None, False)
-    want = F.conv2d(x.double(), w.double()).float() + shift.view(1, -1, 1, 1)
-    assert rel_err(y_ms, want) < 2e-6
-    for shift_, res_, relu, want_bits in ((shift, None, False, False), (None, None, False, False), (shift, res, True, False),
-                                          (shift, res, True, True)):
-        a, ba = run(None, shift_, res_, relu, want_bits)
-        b, bb = run(1, shift_, res_, relu, want_bits)
-        assert torch.equal(a, b), (case[0], shift_ is not None, res_ is not None, relu, want_bits)
-        if want_bits:
-            wa = ba.words.view(M, -1).to(torch.int64) & valid
-            wb = bb.words.view(M, -1).to(torch.int64) & valid
-            assert torch.equal(wa, wb)
-    # consumer side: residual (accumulate into an existing gradient) + a recorded bit mask
-    mask = ops.ReluBits(N_, M, H, W, x.device)
-    mask.words.random_(-2 ** 31, 2 ** 31 - 1, generator=None)
-    a, _ = run(None, None, res, False, mask=mask)
-    b, _ = run(1, None, res, False, mask=mask)
-    assert torch.equal(a, b)
-    assert 0.3 < float((a == 0).float().mean()) < 0.7
-    # in place on the residual, as the backward pass calls it (each element is read and written by the same lane)
-    acc1, acc2 = res.clone(), res.clone()
-    ops.gemm1x1_msweep(x, packed, acc1, None, acc1, mask, False)
-    ops.conv_gemm(x, packed, table, acc2, (H, W), 1, M, K, 1, None, acc2, mask, False, schedule=1)
-    assert torch.equal(acc1, acc2) and torch.equal(acc1, a)
-
-
 def test_reserved_cus_shrink_the_persistent_grid_without_changing_results():
     """dasac_set_reserved_cus(n): the stream-K grid (and the streaming kernels' grid cap) is sized to 256 - n CUs so that RCCL's
     kernels, which the overlapped data-parallel wrapper runs beside the backward GEMMs, do not share CUs with workers that all

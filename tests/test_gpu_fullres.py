@@ -29,8 +29,10 @@ def test_cfg3_resolution_sample_matches_the_oracle(fuse):
     print("parity_fullres:", cmp_, "cores", cores)
     assert cmp_["labelled_frac"] > 0.05                       # the thresholds fire: the label comparison is not vacuous
     assert cmp_["loss_ce_rel"] <= 1e-4
-    assert cmp_["self_ce_rel"] <= 5e-3
-    assert cmp_["label_mismatch_frac"] < 1e-3                 # fp32 probabilities differ at 1e-6: borderline pixels only
+    # bounds = at most 5x what five rounds of boxes measured (self_ce 6.5e-5, 2 of 591 361 labels = 3.4e-6, gradients 2.6e-4 of the
+    # tensor max): a regression of one order of magnitude fails here
+    assert cmp_["self_ce_rel"] <= 5e-4
+    assert cmp_["label_mismatch_frac"] <= 2e-5                # fp32 probabilities differ at 1e-6: borderline pixels only
     assert cmp_["running_conf_max_abs"] <= 1e-6
     # north_star: logits / grads within 1e-3 rel (of the tensor max); free-running gradients carry the borderline-ReLU effect
     # that the fp64 arbitration of test_gpu_models.py explains -- at 591k pixels per plane one flipped unit weighs far less

@@ -102,10 +102,10 @@ def test_refine_avg_pool_golden_g4(golden):
     assert rel_err(aligned, g["avg_pool_teacher_aligned"]) < TOL
 
 
-@pytest.mark.parametrize("shape", [(4, 19, 21, 30), (2, 5, 22, 9), (2, 19, 1, 7), (6, 2, 33, 64)])
+@pytest.mark.parametrize("shape", [(4, 19, 21, 30), (2, 5, 22, 9), (2, 19, 1, 7), (6, 2, 33, 64), (2, 3, 9, 1), (2, 19, 1, 1)])
 def test_warp_back_against_the_oracle(shape):
     """refined[b] = sample(pooled[b // T], theta_inv[b]) * sample(mask[b // T], theta_inv[b]) under random affines (odd and even
-    heights, a single row, few classes)."""
+    heights, a single row, few classes, a single column -- grid_sample accepts any size)."""
     from dasac_hip import ops
     B, C, Hh, W = shape
     Tn = 2

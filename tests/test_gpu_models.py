@@ -214,9 +214,10 @@ def test_vgg16_deeplab_cfg1_golden_g10(golden):
     assert rel_err(outs["logits"], g["logits"]) < 1e-4
     assert rel_err(losses["loss_ce"], g["loss"]) < 1e-5
     named = dict(net.named_parameters())
-    assert rel_err(sampled(named["features.0.weight"].grad), g["g_first"]) < 2e-3
-    assert rel_err(sampled(named["features.42.weight"].grad), g["g_fc6"]) < 2e-3
-    assert rel_err(named["classifier.conv2d_list.2.bias"].grad, g["g_cls_bias"]) < 1e-3
+    errs = (rel_err(sampled(named["features.0.weight"].grad), g["g_first"]), rel_err(sampled(named["features.42.weight"].grad), g["g_fc6"]),
+            rel_err(named["classifier.conv2d_list.2.bias"].grad, g["g_cls_bias"]))
+    print("g10 vgg16-deeplab gradient errors over tensor max:", errs)
+    assert max(errs) < 1e-3                                  # north_star: grads within 1e-3 rel
 
 
 def test_fcn8s_golden_g10(golden):
@@ -231,9 +232,10 @@ def test_fcn8s_golden_g10(golden):
     assert rel_err(outs["logits_up"], g["logits_up"]) < 1e-4
     assert rel_err(losses["loss_ce"], g["loss"]) < 1e-5
     named = dict(net.named_parameters())
-    assert rel_err(sampled(named["vgg_head.0.weight"].grad), g["g_head0"]) < 2e-3
-    assert rel_err(named["score_pool3.weight"].grad.reshape(-1)[:64], g["g_sp3"]) < 2e-3
-    assert rel_err(sampled(named["block1.0.weight"].grad), g["g_first"]) < 2e-3
+    errs = (rel_err(sampled(named["vgg_head.0.weight"].grad), g["g_head0"]), rel_err(named["score_pool3.weight"].grad.reshape(-1)[:64], g["g_sp3"]),
+            rel_err(sampled(named["block1.0.weight"].grad), g["g_first"]))
+    print("g10 fcn8s gradient errors over tensor max:", errs)
+    assert max(errs) < 1e-3                                  # north_star: grads within 1e-3 rel
 
 
 def test_fcn8s_dropout2d_with_injected_masks_vs_oracle():

@@ -54,8 +54,8 @@ def test_g10_vgg16_deeplab_cfg1(golden):
     losses["loss_ce"].sum().backward()
     assert rel_err(outs["logits"], g["logits"]) < 1e-4
     assert rel_err(losses["loss_ce"], g["loss"]) < 1e-5
-    assert rel_err(sampled(sd["features.0.weight"].grad), g["g_first"]) < 2e-3
-    assert rel_err(sampled(sd["features.42.weight"].grad), g["g_fc6"]) < 2e-3
+    assert rel_err(sampled(sd["features.0.weight"].grad), g["g_first"]) < 1e-4
+    assert rel_err(sampled(sd["features.42.weight"].grad), g["g_fc6"]) < 1e-4
     assert rel_err(sd["classifier.conv2d_list.2.bias"].grad, g["g_cls_bias"]) < 1e-3
 
 
@@ -70,9 +70,9 @@ def test_g10_fcn8s(golden):
     losses["loss_ce"].sum().backward()
     assert rel_err(outs["logits_up"], g["logits_up"]) < 1e-4
     assert rel_err(losses["loss_ce"], g["loss"]) < 1e-5
-    assert rel_err(sampled(sd["vgg_head.0.weight"].grad), g["g_head0"]) < 2e-3
-    assert rel_err(sd["score_pool3.weight"].grad.reshape(-1)[:64], g["g_sp3"]) < 2e-3
-    assert rel_err(sampled(sd["block1.0.weight"].grad), g["g_first"]) < 2e-3
+    assert rel_err(sampled(sd["vgg_head.0.weight"].grad), g["g_head0"]) < 1e-4
+    assert rel_err(sd["score_pool3.weight"].grad.reshape(-1)[:64], g["g_sp3"]) < 1e-4
+    assert rel_err(sampled(sd["block1.0.weight"].grad), g["g_first"]) < 1e-4
 
 
 def test_keys_and_param_groups(golden):
