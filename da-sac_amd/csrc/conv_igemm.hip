@@ -33,6 +33,8 @@ constexpr int kThreads = 256;      // 4 waves
 constexpr int kInvalid = 1 << 20;  // dh of a padded table row: never in bounds
 constexpr int kSkWorkersPerCu = 3;                       // persistent 128x128 workers per CU (<=168 registers, 32 KB LDS each; four spill: EXPERIMENTS.md)
 constexpr int kSkWorkers = kNumCu * kSkWorkersPerCu;     // 768, multiple of 8: the grid of every stream-K launch
+constexpr int kTileSlots = kNumCu * 4;                   // resident blocks of the tile-per-block kernel (4 per CU)
+constexpr int kTailSlots = 2048;                         // deposit / flag slots of the split-K tail (SK == 2): 128 MB of workspace
 
 #ifdef DASAC_TRACE_TILES
 // Diagnostic build only (tools/tile_timeline.py): per tile-per-block workgroup four s_memtime stamps -- start, first tile in LDS,
@@ -208,11 +210,22 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // BITS: 0 = fp32 epilogue operands only; 1 = the ReLU epilogue also records its pattern as bits (Epilogue::obits);
 //       2 = the epilogue masks with a recorded bit pattern (Epilogue::mbits).  Separate instantiations, so that the plain
 //       kernels carry none of the extra scalar state.
-template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool STREAMK, bool X3, int BITS = 0>
-__global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
+// SK: 0 = one block per tile; 1 = persistent stream-K (above); 2 = one block per tile for the leading whole rounds of resident
+//     blocks AND, in the same launch, the remaining `tail_tiles` tiles cut into `tail_split` K-ranges of one block each (round 6).
+//     A cut tile's pieces with the LATER K-steps carry the lower block ids -- blocks are dispatched in id order, so they are resident
+//     or done before the piece with the first K-steps (the owner: it adds their deposits and runs the epilogue) even starts, and
+//     they wait for nothing: progress needs no co-residency.  Same sc1 deposits and self-cleaning flags as the persistent kernel,
+//     but at the plain kernel's four blocks per CU (a piece is ONE tile segment: no loop over segments, deposits read a quarter
+//     at a time) and without a second launch: the tail's ramp hides behind the last full round's stragglers.
+template <int BM, int BN, int WAVES_M, int BK, bool FAST, int SK, bool X3, int BITS = 0>
+__global__ __launch_bounds__(kThreads, SK == 1 ? kSkWorkersPerCu : 4) void conv_gemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                       const int4* __restrict__ tab, float* __restrict__ Out,
                                                       GemmGeom g, Epilogue ep, int m_tiles, int n_tiles,
-                                                      float* __restrict__ partial, int* __restrict__ flags) {
+                                                      float* __restrict__ partial, int* __restrict__ flags, int tail_tiles,
+                                                      int tail_split) {
+  constexpr bool STREAMK = SK == 1;      // persistent: a worker loops over tile segments
+  constexpr bool TAIL = SK == 2;
+  constexpr bool HANDOFF = STREAMK || TAIL;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -259,8 +272,8 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
   const __amdgpu_buffer_rsrc_t rmsk = BITS == 2 ? make_rsrc(ep.mbits, g.M * ep.w32 * 4) : make_rsrc(ep.mask ? ep.mask : Out, g.out_bytes);
   const __amdgpu_buffer_rsrc_t rsh = make_rsrc(ep.shift ? ep.shift : Out, ep.shift ? g.M * 4 : 0);
   const bool ragged = (g.M & 7) != 0;
-  const __amdgpu_buffer_rsrc_t rpart = make_rsrc(STREAMK ? (const void*)partial : (const void*)Out,
-                                                 STREAMK ? kSkWorkers * ACC_REGS * kThreads * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rpart = make_rsrc(HANDOFF ? (const void*)partial : (const void*)Out,
+                                                 HANDOFF ? (STREAMK ? kSkWorkers : kTailSlots) * ACC_REGS * kThreads * 4 : 0);
 
   // ---- which part of the iteration space is mine --------------------------------------------
   // block b runs on XCD b%8: tiles (or ranges) that are adjacent -- same activation tile, next M tile --
@@ -285,11 +298,29 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
   } else {
     // each XCD owns a CONTIGUOUS run of pixel tiles (spatial neighbours share halo rows in its L2)
     const int per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
-    const int n_local = slot / m_tiles;
-    const int n_tile = xcd * per_xcd + n_local;
-    if (n_local >= per_xcd || n_tile >= n_tiles) return;
-    it = (n_tile * m_tiles + slot % m_tiles) * KT;
-    it_end = it + KT;
+    const int lead_blocks = per_xcd * kNumXcd * m_tiles;       // == gridDim.x without a tail
+    if (!TAIL || bid < lead_blocks) {
+      const int n_local = slot / m_tiles;
+      const int n_tile = xcd * per_xcd + n_local;
+      if (n_local >= per_xcd || n_tile >= n_tiles) return;
+      it = (n_tile * m_tiles + slot % m_tiles) * KT;
+      it_end = it + KT;
+    } else {
+      // tail piece q: K-range `part` (later ranges first) of tail tile tr; the tail tiles follow the n_tiles leading pixel tiles;
+      // runs of adjacent tiles (the M tiles of a pixel tile, neighbouring pixel tiles) go to one XCD, like the leading part
+      const int q = bid - lead_blocks;
+      const int per_x = (tail_tiles + kNumXcd - 1) / kNumXcd;
+      const int part_rev = q / (per_x * kNumXcd), ql = q - part_rev * (per_x * kNumXcd);
+      const int tl = ql / kNumXcd;                             // ql % kNumXcd == xcd (lead_blocks and per_x * kNumXcd are multiples of 8)
+      const int tr = xcd * per_x + tl;
+      if (tr >= tail_tiles) return;
+      const int part = tail_split - 1 - part_rev;
+      const int tile = n_tiles * m_tiles + tr;
+      // balanced K-ranges: part p holds steps [p*KT/s, (p+1)*KT/s)
+      it = tile * KT + part * KT / tail_split;                 // (KT <= 2^15 or so: no overflow)
+      it_end = tile * KT + (part + 1) * KT / tail_split;
+      my_range = tr * (tail_split - 1) + part - 1;             // deposit / flag slot of a non-owner piece (part >= 1)
+    }
   }
 
   // (a do-while whose back edge exists only in the persistent variant: the tile-per-block kernel runs the body once -- it returned
@@ -392,7 +423,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     // the tile's per-row epilogue operands (consumed only by the worker that runs the epilogue: ks == 0)
     float pro_shift = 0.f;
     unsigned pro_bits[BITS == 2 ? (BN / 32) * BM / kThreads : 1];
-    if (!STREAMK || ks == 0) {
+    if (!HANDOFF || ks == 0) {
       if (t < BM) pro_shift = buf_f32(rsh, (unsigned)(m0 + t) * 4u, 0);      // rows past M (and a null shift: 0 records) read 0
       if constexpr (BITS == 2) {
         static_assert(BITS != 2 || ((BN / 32) * BM) % kThreads == 0, "mask words per tile");
@@ -407,7 +438,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     }
     DASAC_LOAD_TILE(ks);
     DASAC_STORE_TILE(ks & 1);
-    if (!STREAMK || ks == 0) {
+    if (!HANDOFF || ks == 0) {
       if (t < BM) s_shift[t] = pro_shift;
       if (t < BN) s_vo[t] = pro_vo;
       if constexpr (BITS == 2) {
@@ -468,7 +499,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
 #undef DASAC_LOAD_TILE
 #undef DASAC_STORE_TILE
 
-    if (STREAMK) {
+    if (HANDOFF) {
       // Hand-off of a tile cut by range boundaries: the worker holding a tile's LATER K-steps deposits its accumulators in
       // `partial` and raises a flag, the worker holding the FIRST K-steps (the owner) adds the deposits and runs the epilogue.
       // Deposits are agent-scope (sc1) write-through stores read back with sc1 loads -- placement independent (the per-XCD
@@ -477,6 +508,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
       // checked -- changes nothing: 116.2 vs 113.2 us on the layer3 3x3 remainder.  The ~25 us a remainder launch costs
       // beyond its K-steps is ramp, hand-off latency and epilogue, not the 2 x 50 MB of deposit traffic.)
       constexpr int kAux = kAuxSc1;
+      int c_first = 0, c_count = 0;
       if (ks > 0) {
         // partial layout [range][32x32 sub-tile][quarter][thread][4]: 16-byte stores, a wave writes 1 KB contiguous
         const int dst0 = my_range * (ACC_REGS * kThreads * 4);     // bytes; scalar
@@ -501,7 +533,12 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
         // empty (the host picks this schedule only with >= 1 K-step per worker).
         const int tile_end = (tile + 1) * KT;
         int n_contrib = 1;                                     // contributors are my_range + 1 .. my_range + n_contrib
-        while (sk_start(my_range + n_contrib + 1) < tile_end) ++n_contrib;
+        if (TAIL) {                                            // the tile's other pieces: slots tr * (s - 1) + 0 .. s - 2
+          my_range = (tile - n_tiles * m_tiles) * (tail_split - 1) - 1;
+          n_contrib = tail_split - 1;
+        } else {
+          while (sk_start(my_range + n_contrib + 1) < tile_end) ++n_contrib;
+        }
         if (t == 0) {
           // Progress does not need all workers resident: a range deposits at the very START of its work, before it waits for
           // anything, and blocks are dispatched in id order, so the depositor of r is at worst the next block to get a slot.
@@ -520,13 +557,22 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
           }
         }
         __syncthreads();
-        for (int r = my_range + 1; r <= my_range + n_contrib; ++r) {
+        c_first = my_range + 1;
+        c_count = n_contrib;
+      }
+      // the owner adds its contributors' deposits (a loop that runs zero times for everybody else: written outside the branches
+      // above so that the accumulators are loop-carried in place instead of being merged -- copied, at 128 registers spilled --
+      // at the join of three paths)
+      {
+        for (int r = c_first; r < c_first + c_count; ++r) {
           const int src0 = r * (ACC_REGS * kThreads * 4);
           // half a deposit in flight at a time: 8 x 16-byte loads per thread (a whole one -- 64 more registers next to the 64
-          // accumulators -- does not fit the 168 registers of 3 workers per CU without spilling)
-          constexpr int QH = TM * TN * 2;
+          // accumulators -- does not fit the 168 registers of 3 workers per CU without spilling); a quarter in the tail pieces'
+          // 128-register kernel
+          constexpr int NB = TAIL ? 4 : 2;
+          constexpr int QH = TM * TN * 4 / NB;
 #pragma unroll
-          for (int hb = 0; hb < 2; ++hb) {
+          for (int hb = 0; hb < NB; ++hb) {
             f32x4 pv[QH];
 #pragma unroll
             for (int q = 0; q < QH; ++q) {
@@ -549,7 +595,7 @@ __global__ __launch_bounds__(kThreads, STREAMK ? kSkWorkersPerCu : 4) void conv_
     // The BN scale is already folded into the packed weights.  All traffic goes through buffer
     // descriptors: per-lane voffset = pixel position (+ the lane-half's 4-row step), the row offset is
     // scalar; loads of a 16-row group are issued as one batch before any of them is consumed.
-    const bool deposited = STREAMK && ks > 0;                // this worker only contributed a partial sum
+    const bool deposited = HANDOFF && ks > 0;                // this worker only contributed a partial sum
     DASAC_STAMP(2);
     // (Round 5, measured: __builtin_amdgcn_s_setprio(3) for the epilogue changes nothing -- 21.0 vs 21.3 us from the end of the K loop to
     // the last store issued, profiles/r5_epilogue_anatomy.txt: a wave with an MFMA ready is served first whatever the priorities are.
@@ -743,7 +789,7 @@ constexpr int kWgPitch = 36;   // row pitch (floats): 16-byte aligned rows, 16 c
 // gives the head as an fp32 bit pattern directly) and stored with 16-bit writes into [octet of 8 pixels][row][8]
 // operand words; the octet pitch rows+2 keeps the 64 lanes of a store on distinct banks and the 16-byte MFMA
 // operand reads of consecutive rows contiguous.
-template <int BM, int BN, int WAVES_M, bool FAST, bool X3, bool QUAD = false>
+template <int BM, int BN, int WAVES_M, bool FAST, bool X3, bool QUAD = false, bool QTAP = false>
 __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restrict__ dZ, const float* __restrict__ X,
                                                        const int4* __restrict__ tab, float* __restrict__ P,
                                                        float* __restrict__ Psum, GemmGeom g, int m_tiles, int k_tiles,
@@ -813,6 +859,14 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     // leave the split or the image (the dz / x tensors are [N][rows][OH*OW]: a quad may straddle two images) send their
     // whole wave through a per-element path for that step.
     static_assert(FAST && !X3 && BM % 32 == 0 && BN % 32 == 0, "quad loader: fp32, one tap per k tile, 32-row passes");
+    static_assert(!QTAP || QUAD, "the tap variant extends the quad loader");
+    // QTAP (round 6): the same loader for "same"-padded stride-1 k x k convolutions (host: H == OH, W == OW >= 4, one tap per k
+    // tile).  Tap (dh, dw) reads x at flat position p + dh*W + dw of the SAME plane -- contiguous for a lane's four consecutive
+    // pixels whatever row boundary lies between them -- so the gathered operand takes 16-byte loads too; what the tap changes is
+    // VALIDITY (the convolution's zero padding), and that is per pixel: out-of-image taps are zeroed after the load.  Most quads
+    // need nothing (one compare chain + a ballot); only waves that touch a row end or the first / last dh rows run the
+    // per-element masks.  Earlier rounds kept these layers on the dword loader because "tap shifts break 16-byte runs at every
+    // 97-pixel row": they break ALIGNMENT (dwordx4 needs 4 bytes) and validity, not contiguity.
     constexpr int AQ = BM / 32, BQ = BN / 32;
     const int pq = t & 7, prow4 = t >> 3;                  // loader: pixel quad of the step, row within a 32-row pass
     f32x4 qa[AQ], qb[BQ];
@@ -822,21 +876,48 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     const int zimg_q = g.M * OHW;
     int pix = p_begin + 4 * pq;                            // first pixel of this thread's quad (advanced by kWgPix per step)
     int pn = pix / OHW, prr = pix - pn * OHW;              // image, flat position inside it
+    int qoh = 0, qow = 0;                                  // QTAP: row / column of the quad's first pixel
+    if (QTAP) {
+      qoh = prr / g.OW;
+      qow = prr - qoh * g.OW;
+    }
+    const int tap_off = QTAP ? e0.x - e0.w : 0;            // dh*W + dw
+    // x offset of (image, k tile's first channel + prow4, quad start + tap), in elements.  The k tile's first channel rides in the
+    // per-lane part so that it is negative only in the first rows of image 0, channel 0 (those quads take the per-element path:
+    // a wrapped unsigned offset fails the range check whatever the scalar offset adds)
 #define DASAC_WGQ_LOAD()                                                                             \
   {                                                                                                  \
-    const bool whole = (pix + 3 < p_end) & (prr + 3 < OHW);                                          \
+    const int xo = pn * g.CxHW + (QTAP ? e0.w : 0) + prr + tap_off + prow4 * planeHW;                \
+    const bool whole = (pix + 3 < p_end) & (prr + 3 < OHW) & (!QTAP || xo >= 0);                     \
     if (__builtin_amdgcn_ballot_w64(!whole) == 0) {                                                  \
       const unsigned vz = (unsigned)(pn * zimg_q + prr + prow4 * OHW) * 4u;                          \
-      const unsigned vx = (unsigned)(pn * g.CxHW + prr + prow4 * planeHW) * 4u;                      \
+      const unsigned vx = (unsigned)xo * 4u;                                                         \
       _Pragma("unroll") for (int i = 0; i < AQ; ++i) qa[i] = buf_f32x4(rz, vz, (m0 + i * 32) * OHW * 4); \
-      _Pragma("unroll") for (int i = 0; i < BQ; ++i) qb[i] = buf_f32x4(rx, vx, (e0.w + i * 32 * planeHW) * 4); \
+      _Pragma("unroll") for (int i = 0; i < BQ; ++i) qb[i] = buf_f32x4(rx, vx, ((QTAP ? 0 : e0.w) + i * 32 * planeHW) * 4); \
+      if (QTAP) {                                                                                    \
+        const int c0 = qow + e0.z;                                                                   \
+        const bool inside = ((unsigned)(qoh + e0.y) < (unsigned)g.H) & (c0 >= 0) & (c0 + 3 < g.W) & (qow + 3 < g.OW); \
+        if (__builtin_amdgcn_ballot_w64(!inside) != 0) {                                             \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+            int ow_e = qow + e, oh_e = qoh;                                                          \
+            if (ow_e >= g.OW) { ow_e -= g.OW; ++oh_e; }                                              \
+            const bool ok = ((unsigned)(oh_e + e0.y) < (unsigned)g.H) & ((unsigned)(ow_e + e0.z) < (unsigned)g.W); \
+            _Pragma("unroll") for (int i = 0; i < BQ; ++i) qb[i][e] = ok ? qb[i][e] : 0.f;           \
+          }                                                                                          \
+        }                                                                                            \
+      }                                                                                              \
     } else {                                                                                         \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
         int re = prr + e, ne = pn;                                                                   \
         while (re >= OHW) { re -= OHW; ++ne; } /* maps smaller than a quad: several images per quad */ \
         const bool ve = pix + e < p_end;                                                             \
+        bool vt = ve;                                                                                \
+        if (QTAP) {                                                                                  \
+          const int oh_e = re / g.OW, ow_e = re - oh_e * g.OW;                                       \
+          vt = ve & ((unsigned)(oh_e + e0.y) < (unsigned)g.H) & ((unsigned)(ow_e + e0.z) < (unsigned)g.W); \
+        }                                                                                            \
         const unsigned vz = ve ? (unsigned)(ne * zimg_q + re + prow4 * OHW) * 4u : kPoison;          \
-        const unsigned vx = ve ? (unsigned)(ne * g.CxHW + re + prow4 * planeHW) * 4u : kPoison;      \
+        const unsigned vx = vt ? (unsigned)(ne * g.CxHW + re + tap_off + prow4 * planeHW) * 4u : kPoison; \
         _Pragma("unroll") for (int i = 0; i < AQ; ++i) qa[i][e] = buf_f32(rz, vz, (m0 + i * 32) * OHW * 4); \
         _Pragma("unroll") for (int i = 0; i < BQ; ++i) qb[i][e] = buf_f32(rx, vx, (e0.w + i * 32 * planeHW) * 4); \
       }                                                                                              \
@@ -846,7 +927,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad(const float* __restric
     }                                                                                                \
     pix += kWgPix;                                                                                   \
     prr += kWgPix;                                                                                   \
-    while (prr >= OHW) { prr -= OHW; ++pn; }                                                         \
+    if (QTAP) {                                                                                      \
+      qow += kWgPix;                                                                                 \
+      while (qow >= g.OW) { qow -= g.OW; ++qoh; }                                                    \
+    }                                                                                                \
+    while (prr >= OHW) { prr -= OHW; ++pn; if (QTAP) qoh -= g.OH; }                                  \
   }
 #define DASAC_WGQ_STORE()                                                                            \
   {                                                                                                  \
@@ -1374,6 +1459,12 @@ static bool persistent_grid_fits() {
   return ok;
 }
 
+// (experiment switch of round 6, removed once the A/B is recorded)
+static bool tail_enabled() {
+  static const int on = getenv("DASAC_TAIL") ? atoi(getenv("DASAC_TAIL")) : 1;
+  return on != 0;
+}
+
 // workers of a persistent stream-K launch: 3 per CU on the CUs this process does not leave to overlapped collectives.  `reserved` is
 // read ONCE per launch decision (reserved_cus()) and handed through: a concurrent dasac_set_reserved_cus must not make the
 // eligibility test, the schedule choice and the grid size of one launch disagree.
@@ -1392,27 +1483,65 @@ static bool want_streamk(int tiles, int k_steps, int reserved) {
   return k_steps >= 64 ? eff < 0.93 : (k_steps >= 16 && eff < 0.6);
 }
 
-// `n_tiles` pixel tiles starting at g.n_tile0; schedule 0 = pick (want_streamk), 1 = one block per tile, 2 = stream-K
+// Split-K tail (SK == 2) of a launch over ALL n_tiles pixel tiles: the leading whole rounds of resident blocks run one block per
+// tile, the remaining R tiles are cut into `split` K-ranges so that the pieces fill (a whole number of) rounds again.  Chosen for
+// the shapes the persistent schedule was chosen for in rounds 2-5 (want_streamk) when at least one whole round leads.  The split
+// minimises rounds x (K-steps per piece + a piece's fixed cost: prologue, deposit or epilogue ~ 6 K-steps).  Returns 0 = no tail.
+static int tail_plan(int m_tiles, int n_tiles, int k_steps, int reserved, int& lead_n) {
+  const int tiles = m_tiles * n_tiles;
+  if (!want_streamk(tiles, k_steps, reserved)) return 0;
+  lead_n = (tiles / kTileSlots) * kTileSlots / m_tiles;          // pixel tiles of the leading whole rounds
+  if (lead_n <= 0 || lead_n >= n_tiles) return 0;
+  const int R = (n_tiles - lead_n) * m_tiles;
+  int best = 0;
+  double best_cost = 0.0;
+  for (int sp = 1; sp <= 8 && sp * 8 <= k_steps; ++sp) {
+    if ((long long)R * (sp - 1) > kTailSlots) break;
+    const int rounds = (R * sp + kTileSlots - 1) / kTileSlots;
+    const double cost = rounds * ((double)k_steps / sp + 6.0);
+    if (best == 0 || cost < best_cost - 1e-9) {
+      best = sp;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+// `n_tiles` pixel tiles starting at g.n_tile0; schedule 0 = pick (split-K tail over a whole tensor, else want_streamk), 1 = one
+// block per tile, 2 = stream-K
 template <int BM, int BN, int WAVES_M, int BK, bool FAST, bool X3 = false, int BITS = 0>
 static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* Out, const GemmGeom& g,
                        const Epilogue& ep, int n_tiles, int schedule, void* workspace, size_t ws_bytes, hipStream_t s) {
   const int m_tiles = (g.M + BM - 1) / BM;
   if ((long long)m_tiles * (n_tiles + kNumXcd) * (g.Kpad / BK) >= (1ll << 31)) return fail(DASAC_EINVAL, "conv_gemm: iteration space exceeds 2^31");
   const int reserved = reserved_cus();
+  const size_t part_bytes = (size_t)(kTailSlots > kSkWorkers ? kTailSlots : kSkWorkers) * (BM * BN) * sizeof(float);
+  const size_t need = part_bytes + (size_t)(kTailSlots + 1) * sizeof(int);
+  float* partial = reinterpret_cast<float*>(workspace);
+  int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
+  if constexpr (BM == 128 && BITS != 3) {
+    const bool whole = g.n_tile0 == 0 && (long long)n_tiles * BN >= g.Npix;
+    int lead_n = 0;
+    const int split = (schedule == 0 && whole && workspace && persistent_grid_fits() && tail_enabled()) ? tail_plan(m_tiles, n_tiles, g.Kpad / BK, reserved, lead_n) : 0;
+    if (split > 0) {
+      if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
+      const int R = (n_tiles - lead_n) * m_tiles;
+      const int lead_pad = (lead_n + kNumXcd - 1) / kNumXcd * kNumXcd, r_pad = (R + kNumXcd - 1) / kNumXcd * kNumXcd;
+      hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, 2, X3, BITS>), dim3(lead_pad * m_tiles + r_pad * split), dim3(kThreads), 0, s, X, Wp,
+                         tab, Out, g, ep, m_tiles, lead_n, partial, flags, R, split);
+      return DASAC_OK;
+    }
+  }
   const bool sk_ok = BM == 128 && workspace && (long long)m_tiles * n_tiles * (g.Kpad / BK) >= sk_workers(reserved) && persistent_grid_fits();
   if (sk_ok && (schedule == 2 || (schedule == 0 && want_streamk(m_tiles * n_tiles, g.Kpad / BK, reserved)))) {
-    const size_t part_bytes = (size_t)kSkWorkers * (BM * BN) * sizeof(float);
-    const size_t need = part_bytes + (size_t)(kSkWorkers + 1) * sizeof(int);
     if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
-    float* partial = reinterpret_cast<float*>(workspace);
-    int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
-    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, true, X3, BITS>), dim3(sk_workers(reserved)), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
-                       ep, m_tiles, n_tiles, partial, flags);
+    hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, 1, X3, BITS>), dim3(sk_workers(reserved)), dim3(kThreads), 0, s, X, Wp, tab, Out, g,
+                       ep, m_tiles, n_tiles, partial, flags, 0, 1);
     return DASAC_OK;
   }
   const int n_tiles_pad = (n_tiles + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, false, X3, BITS>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp,
-                     tab, Out, g, ep, m_tiles, n_tiles, nullptr, nullptr);
+  hipLaunchKernelGGL((conv_gemm<BM, BN, WAVES_M, BK, FAST, 0, X3, BITS>), dim3(n_tiles_pad * m_tiles), dim3(kThreads), 0, s, X, Wp,
+                     tab, Out, g, ep, m_tiles, n_tiles, nullptr, nullptr, 0, 1);
   return DASAC_OK;
 }
 
@@ -1512,7 +1641,16 @@ extern "C" int dasac_conv_gemm_plan(int Nb, int OH, int OW, int M, int K) {
 }
 
 extern "C" size_t dasac_conv_gemm_workspace(void) {
-  return (size_t)kSkWorkers * 128 * 128 * sizeof(float) + (size_t)(kSkWorkers + 1) * sizeof(int);
+  return (size_t)(kTailSlots > kSkWorkers ? kTailSlots : kSkWorkers) * 128 * 128 * sizeof(float) + (size_t)(kTailSlots + 1) * sizeof(int);
+}
+
+// K-ranges per tail tile when dasac_conv_gemm (schedule 0, whole tensor, workspace given) runs this shape as ONE launch of whole
+// rounds of tile-per-block workgroups + a split-K tail; 0 = it does not (then dasac_conv_gemm_schedule tells the rest)
+extern "C" int dasac_conv_gemm_tail_split(int Nb, int OH, int OW, int M, int K) {
+  const int Mpad = dasac_conv_mpad(M);
+  if (pick_bm(Mpad) != 128 || !persistent_grid_fits() || !tail_enabled()) return 0;
+  int lead_n = 0;
+  return tail_plan((M + 127) / 128, (int)(((int64_t)Nb * OH * OW + 127) / 128), (K + kBK - 1) / kBK, reserved_cus(), lead_n);
 }
 
 #ifdef DASAC_TRACE_TILES
@@ -1721,12 +1859,19 @@ static int conv_wgrad_impl(bool x3, const float* dz, const float* x, const int32
   switch (bm) {
     case 128: {
       // 1x1 stride-1 layers: both operands are plain [row][pixel] matrices -> four pixels per lane (conv_wgrad<..., QUAD>)
-      const bool quad = fast && !x3 && K == Cx && stride == 1 && H == OH && W == OW && M % 128 == 0;   // one tap, no padding
-      if (quad) {
+      const bool same = fast && !x3 && stride == 1 && H == OH && W == OW && M % 128 == 0;
+      const bool quad = same && K == Cx;                                                   // one tap, no padding
+      // "same"-padded k x k layers (every 3x3 of the bottlenecks): the quad loader with per-pixel tap validity (QTAP)
+      const bool qtap = same && K > Cx && K % Cx == 0 && W >= 4;
+      if (quad || qtap) {
         const int m_tiles = g.Mpad / 128, k_tiles = g.Kpad / 128;
         const int grid = (m_tiles * k_tiles * splits + kNumXcd - 1) / kNumXcd * kNumXcd;
-        hipLaunchKernelGGL((conv_wgrad<128, 128, 2, true, false, true>), dim3(grid), dim3(kThreads), 0, s, dz, x, tab, P, Psum, g,
-                           m_tiles, k_tiles, splits, per);
+        if (quad)
+          hipLaunchKernelGGL((conv_wgrad<128, 128, 2, true, false, true, false>), dim3(grid), dim3(kThreads), 0, s, dz, x, tab, P, Psum, g,
+                             m_tiles, k_tiles, splits, per);
+        else
+          hipLaunchKernelGGL((conv_wgrad<128, 128, 2, true, false, true, true>), dim3(grid), dim3(kThreads), 0, s, dz, x, tab, P, Psum, g,
+                             m_tiles, k_tiles, splits, per);
       } else if (fast) launch_wgrad<128, 128, 2, true>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       else launch_wgrad<128, 128, 2, false>(x3, dz, x, tab, P, Psum, g, splits, per, s);
       break;

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "dasac_conv_gemm_workspace": (_sz, []),
     "dasac_conv_gemm_schedule": (_i, [_i, _i, _i, _i, _i]),
     "dasac_conv_gemm_plan": (_i, [_i, _i, _i, _i, _i]),
+    "dasac_conv_gemm_tail_split": (_i, [_i, _i, _i, _i, _i]),
     "dasac_conv_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dasac_conv_wgrad": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
     "dasac_conv_wgrad_x3": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),
@@ -104,6 +105,8 @@ def load():
                              "g.build()'`; there is no CPU fallback".format(LIB_PATH))
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
+            if not hasattr(lib, name) and os.environ.get("DASAC_LIB"):
+                continue                      # an older build of the library named by DASAC_LIB (A/B measurements): newer entry points absent
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         _lib = lib

@@ -24,6 +24,14 @@ CASES = [
     # over 117-pixel images, and a strided 1x1 (dZ grid != input grid)
     ("3x3_d2_fast_ragged", 128, 200, [(3, 3, 2, 2)], 1, (3, 9, 13)),
     ("1x1_s2_fast", 128, 256, [(1, 1, 1, 0)], 2, (2, 25, 33)),
+    # round 6: the quad loader with per-pixel tap validity (conv_wgrad<..., QUAD, QTAP>: "same"-padded k x k, stride 1, Cin % 128 == 0,
+    # Cout % 128 == 0, W >= 4): images smaller than a step with quads that straddle them, the narrowest maps (every quad wraps a
+    # row; dilation beyond the map: most taps fall outside), a 5x5, and a launch with several pixel splits and two m / k tiles per tap
+    ("3x3_qtap_images", 128, 256, [(3, 3, 2, 2)], 1, (3, 9, 13)),
+    ("3x3_qtap_w4", 128, 128, [(3, 3, 1, 1)], 1, (2, 6, 4)),
+    ("3x3_qtap_w5_d3", 256, 128, [(3, 3, 3, 3)], 1, (2, 7, 5)),
+    ("5x5_qtap", 128, 128, [(5, 5, 1, 2)], 1, (1, 12, 10)),
+    ("3x3_qtap_splits", 256, 256, [(3, 3, 2, 2)], 1, (2, 40, 37)),
     ("3x3_d1_c19", 48, 19, [(3, 3, 1, 1)], 1, (3, 9, 13)),
     ("7x7_s2_stem", 3, 64, [(7, 7, 1, 3)], 2, (2, 65, 49)),
     ("aspp4", 96, 19, [(3, 3, 6, 6), (3, 3, 12, 12), (3, 3, 18, 18), (3, 3, 24, 24)], 1, (2, 17, 21)),
@@ -282,6 +290,62 @@ def test_relu_bit_masks_equal_the_fp32_pattern(cin, cout, k, dil, shape):
         b = ops.conv_dgrad(spec2, dz, [w2], (H, W), res=res, mask=bits)
         assert torch.equal(a, b)
         assert float((a == 0).float().mean()) > 0.2
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,shape,want_split", [
+    (256, 256, 3, 2, (8, 97, 97), 6),        # layer3 3x3, one student pass: 1178 tiles = 1024 + 154 x 6 K-ranges of 24 steps
+    (1024, 256, 1, 1, (8, 97, 97), 6),       # conv1 of layer3: 64 K-steps
+    (512, 512, 3, 4, (8, 97, 97), 3),        # layer4 3x3: 2356 tiles = 2048 + 308 x 3
+    (2048, 512, 1, 1, (16, 97, 97), 3),      # 4708 tiles = 4096 + 612 x 3: the pieces take TWO rounds of resident blocks
+])
+def test_split_k_tail_in_the_tile_launch(cin, cout, k, dil, shape, want_split):
+    """Round 6: a long-K convolution whose tile count leaves a ragged last round runs as ONE launch -- whole rounds one block per
+    tile, the remaining tiles cut into K-ranges (conv_gemm<SK = 2>: later ranges deposit, the first range's block adds and runs the
+    epilogue).  Against the plain one-block-per-tile launch (summation order of the cut tiles differs: 1e-6), for every epilogue
+    the network uses; two runs give the same bits (fixed ranges, fixed order of the deposits); the recorded ReLU bits follow
+    the stored values; the hand-off flags are left clean."""
+    from dasac_hip import ops
+    lib = ops.L.load()
+    N_, H, W = shape
+    assert lib.dasac_conv_gemm_tail_split(N_, H, W, cout, cin * k * k) == want_split
+    g = torch.Generator().manual_seed(cin + cout + k)
+    spec = ops.ConvSpec(cin, cout, [(k, k, dil, dil * (k // 2))], 1)
+    x = torch.randn(N_, cin, H, W, generator=g).cuda()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda()
+    shift = (torch.randn(cout, generator=g) * 0.1).cuda()
+    res = torch.randn(N_, cout, H, W, generator=g).cuda()
+    order = ops.gemm_order(spec, False)
+    table, packed = ops.conv_table(spec, H, W, False, x.device, order), ops.conv_pack(spec, [w], False, None, order=order)
+    mask = ops.ReluBits(N_, cout, H, W, x.device)
+    mask.words.random_(-2 ** 31, 2 ** 31 - 1)
+
+    def run(schedule, shift_, res_, relu, want_bits=False, mask_=None):
+        out = torch.full((N_, cout, H, W), float("nan"), device="cuda")
+        bits = None
+        if want_bits:
+            bits = ops.ReluBits(N_, cout, H, W, x.device)
+            bits.words.fill_(0x55555555)
+        ops.conv_gemm(x, packed, table, out, (H, W), 1, cout, spec.K, 1, shift_, res_, mask_, relu, bits_out=bits, schedule=schedule)
+        return out, bits
+
+    for shift_, res_, relu, want_bits, mask_ in ((None, None, False, False, None), (shift, res, True, True, None), (None, res, False, False, mask)):
+        a, ba = run(None, shift_, res_, relu, want_bits, mask_)
+        b, bb = run(1, shift_, res_, relu, want_bits, mask_)
+        a2, _ = run(None, shift_, res_, relu, want_bits, mask_)
+        assert not torch.isnan(a).any()
+        assert rel_err(a, b) < 2e-6
+        assert torch.equal(a, a2)
+        assert float((a != b).float().mean()) < 0.5          # the leading rounds run the very same code: equal bits there
+        if want_bits:
+            pos = (a > 0).permute(1, 0, 2, 3).reshape(cout, -1)
+            npix = N_ * H * W
+            idx = torch.arange(npix, device="cuda")
+            got = (ba.words.view(cout, -1)[:, idx >> 5].to(torch.int64) >> (idx & 31)) & 1
+            assert torch.equal(got.bool(), pos)
+    ws = ops.L.workspace(lib.dasac_conv_gemm_workspace(), x.device, owner="conv_gemm")
+    torch.cuda.synchronize()
+    flags = ws[ws.numel() - 4 * 2049:].view(torch.int32)
+    assert int(flags.abs().sum()) == 0                       # self-cleaning flags: every raised flag was taken down by its owner
 
 
 STATS_CASES = [

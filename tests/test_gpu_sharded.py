@@ -136,26 +136,36 @@ def test_view_sharded_sac_iterations_vs_oracle(case):
         p.join(120)
         assert p.exitcode == 0
     fired = 0
+    bad = []          # every violated bound of every (rank, iteration): a failure shows the whole picture, not the first symptom
+
+    def check(ok, *what):
+        if not ok:
+            bad.append(what)
+
+    close = lambda x, y, rel, abs_=0.0: abs(x - y) <= max(rel * abs(y), abs_)
     for r in range(WORLD):
         rec_r, params_r = ref[r]
         for it in range(ITERS):
             a, b = got[r][1][it], rec_r[it]
-            assert a["loss_ce"] == pytest.approx(b["loss_ce"], rel=1e-4), (r, it)
-            assert a["teacher_diff"] == pytest.approx(b["teacher_diff"], rel=2e-3, abs=1e-6), (r, it)
-            assert a["self_ce"] == pytest.approx(b["self_ce"], rel=5e-3, abs=1e-6), (r, it)
-            assert rel_err(a["refined"], b["refined"]) < 1e-4, (r, it)
-            assert rel_err(a["aligned"], b["aligned"]) < 1e-4, (r, it)
-            assert rel_err(a["chi"], b["chi"]) < 1e-4, (r, it)
+            # inputs of the loss first (class prior, aligned and fused probabilities, labels), then the losses built on them
+            check(rel_err(a["chi"], b["chi"]) < 1e-4, r, it, "chi", rel_err(a["chi"], b["chi"]))
+            check(rel_err(a["aligned"], b["aligned"]) < 1e-4, r, it, "aligned", rel_err(a["aligned"], b["aligned"]))
+            check(rel_err(a["refined"], b["refined"]) < 1e-4, r, it, "refined", rel_err(a["refined"], b["refined"]))
             lab = torch.from_numpy(a["labels"])
             assert lab.shape == b["labels"].shape and lab.shape[0] == GROUPS * VIEWS // WORLD
-            assert float((lab != b["labels"]).float().mean()) < 1e-3, (r, it)
+            mism = float((lab != b["labels"]).float().mean())
+            check(mism < 1e-3, r, it, "labels", mism, int((lab != 255).sum()), int((b["labels"] != 255).sum()))
             fired += int((lab != 255).sum())
+            check(close(a["loss_ce"], b["loss_ce"], 1e-4), r, it, "loss_ce", a["loss_ce"], b["loss_ce"])
+            check(close(a["teacher_diff"], b["teacher_diff"], 2e-3, 1e-6), r, it, "teacher_diff", a["teacher_diff"], b["teacher_diff"])
+            check(close(a["self_ce"], b["self_ce"], 5e-3, 1e-6), r, it, "self_ce", a["self_ce"], b["self_ce"])
             # train.py:243-246: the logged value is the mean over ranks
             for k in ("self_ce", "teacher_diff", "tgt_loss_ce"):
                 mean_k = sum(got[w][1][it][k] for w in range(WORLD)) / WORLD
-                assert a["logged"][k.replace("tgt_", "")] == pytest.approx(mean_k, rel=1e-5, abs=1e-7), (r, it, k)
+                check(close(a["logged"][k.replace("tgt_", "")], mean_k, 1e-5, 1e-7), r, it, "logged " + k)
         for k, v in params_r.items():
-            assert rel_err(got[r][2][k], v) < 2e-4, (r, k)
+            check(rel_err(got[r][2][k], v) < 2e-4, r, "param", k, rel_err(got[r][2][k], v))
+    assert not bad, "\n".join(str(x) for x in bad)
     assert fired > 0, "no pseudo label fired: the test would not exercise the loss path"
     # quirk 5: after the last forward the ranks hold different chi (local prior updates); identical parameters though
     for k in got[0][2]:
