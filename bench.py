@@ -231,6 +231,55 @@ def head_parity_fullres(size=769, groups=2, views=4, device=None, seed=17):
     return dt, cmp_
 
 
+def pillow_views_ms(hw, n_views, seed=0):
+    """What the reference's DataLoader worker does per target image after the base crop (dataloader_target.py:281-306), timed
+    with Pillow itself on ONE host thread: per view hflip (p = .5) + zoom window crop -> resize back (BILINEAR image, NEAREST
+    label and mask; tf_target.py:141-239), GaussianBlur(radius ~ U(.1, 2)), colour jitter (p = .5: brightness, contrast,
+    saturation, hue through HSV) and greyscale (p = .2) on the student's copy (tf_target.py:331-390), ToTensor + Normalize of both
+    copies.  A CPU comparator for `ms_per_step_with_device_views` (not a parity oracle: the bit-exact one is oracle/views_ref.py)."""
+    import random
+    import numpy as np
+    from PIL import Image, ImageEnhance, ImageFilter
+    H, W = hw
+    rng = random.Random(seed)
+    gen = np.random.RandomState(seed)
+    image = Image.fromarray(gen.randint(0, 256, (H, W, 3)).astype(np.uint8))
+    label = Image.fromarray(gen.randint(0, 19, (H, W)).astype(np.uint8))
+    mask = Image.fromarray((gen.rand(H, W) < 0.02).astype(np.uint8))
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    t0 = time.perf_counter()
+    for k in range(n_views):
+        im, lb, mk = image, label, mask
+        if rng.random() > 0.5:
+            im, lb, mk = (t.transpose(Image.FLIP_LEFT_RIGHT) for t in (im, lb, mk))
+        if k > 0:
+            sc = rng.uniform(0.5, 1.0)
+            h, w = int(sc * H), int(sc * W)
+            ii, jj = rng.randint(0, H - h), rng.randint(0, W - w)
+            box = (jj, ii, jj + w, ii + h)
+            im = im.crop(box).resize((W, H), Image.BILINEAR)
+            lb = lb.crop(box).resize((W, H), Image.NEAREST)
+            mk = mk.crop(box).resize((W, H), Image.NEAREST)
+        im1 = im.filter(ImageFilter.GaussianBlur(rng.uniform(0.1, 2.0)))
+        if rng.random() < 0.5:
+            im1 = ImageEnhance.Brightness(im1).enhance(rng.uniform(0.6, 1.4))
+            im1 = ImageEnhance.Contrast(im1).enhance(rng.uniform(0.6, 1.4))
+            im1 = ImageEnhance.Color(im1).enhance(rng.uniform(0.6, 1.4))
+            hsv = np.array(im1.convert("HSV"))
+            hsv[..., 0] += np.uint8(int(rng.uniform(-0.1, 0.1) * 255))
+            im1 = Image.fromarray(hsv, "HSV").convert("RGB")
+        if rng.random() < 0.2:
+            im1 = im1.convert("L").convert("RGB")
+        m = np.asarray(mk) != 0
+        for src_ in (im1, im):
+            f = (np.asarray(src_, np.float32) / 255.0 - mean) / std
+            f[m] = 0.0
+            np.ascontiguousarray(f.transpose(2, 0, 1))
+        g_ = np.asarray(lb).astype(np.int64)
+        g_[m] = -1
+    return (time.perf_counter() - t0) * 1e3
+
+
 def time_other_config(config, dev, steps=5, warmup=1):
     """cfg-2 / cfg-5 of BASELINE.json in the driver-timed process: `steps` un-instrumented steps between
     fences -> ms_per_step; one more step with HIP events around the GEMM launches -> algorithmic conv TFLOP per step, so that
@@ -254,25 +303,36 @@ def time_other_config(config, dev, steps=5, warmup=1):
         driver.calibrate_classifier(net, src[0][:1])
     src = (src[0], driver.self_consistent_labels(net, src[0]))
 
+    fuse = {"on": False}
+
     def step(i):
         if baseline:
             return driver.baseline_train_iteration(net, optim, src, tgt[0])
         t = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])
-        return driver.sac_train_iteration(net, optim, src, t, views, update_teacher=(i == 0), lr_target=cfg.LR_TARGET, fuse_passes=True)
+        return driver.sac_train_iteration(net, optim, src, t, views, update_teacher=(i == 0), lr_target=cfg.LR_TARGET, fuse_passes=fuse["on"])
 
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(warmup + i)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    def timed(first):
+        for i in range(warmup):
+            step(first + i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(first + warmup + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    ms = timed(0)                               # the module API as train.py calls it (two student passes in SAC mode)
+    ms_fused = None
+    if not baseline:
+        fuse["on"] = True
+        ms_fused = round(timed(warmup + steps), 3)
+        fuse["on"] = False
     ops.PROFILE.start()
-    step(warmup + steps)
+    step(2 * (warmup + steps))
     prof = ops.PROFILE.stop()
     tflop = sum(v["flops"] for v in prof.values()) / 1e12
-    return {"ms_per_step": round(ms, 3), "images_per_sec": round(batch / ms * 1e3, 3), "conv_tflop_per_step": round(tflop, 3),
+    return {"ms_per_step": round(ms, 3), "ms_per_step_fused_schedule": ms_fused,
+            "images_per_sec": round(batch / ms * 1e3, 3), "conv_tflop_per_step": round(tflop, 3),
             "tflops": round(tflop / ms * 1e3, 2), "frac_of_fp32_matrix_peak": round(tflop / ms * 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
             "workload": "{} source + {}x{} target crops @{}x{}, {}".format(batch, groups, views, hw[0], hw[1],
                                                                           "baseline/AdaBN, batch-statistics BN" if baseline else arch + " + SAC"),
@@ -311,9 +371,12 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="arithmetic of the forward/data-gradient GEMMs: exact fp32 MFMA (default, the reference's arithmetic) or the "
                          "opt-in split-bf16 path (3 bf16 MFMAs per product, fp32 accumulate)")
-    ap.add_argument("--two-pass", action="store_true",
-                    help="run the student's source and target passes one after the other (the reference's call order, train.py:266-298) "
-                         "instead of once over the concatenated batch (SAC.forward_fused: same gradient sum, see DESIGN 5)")
+    ap.add_argument("--fused", action="store_true",
+                    help="time the FUSED student schedule as the headline (SAC.forward_fused: source + target crops in one student pass and "
+                         "one backward -- the same gradient sum, DESIGN 5).  Default since round 6: the module API exactly as the reference's "
+                         "train.py calls it (net(image, masks) + backward, net(frames1, ..., use_teacher=True) + backward, train.py:128-133,"
+                         "219-233); the fused schedule is then reported next to it as `value_fused_schedule`")
+    ap.add_argument("--two-pass", action="store_true", help="(default since round 6; kept for old command lines)")
     ap.add_argument("--alt", action="store_true", help="also run the steps once in the other precision (reported as \"alt\", no credit)")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"],
                     help="cfg3 (default, the headline): RN101+SAC 8+2x4 crops @769^2; cfg2: RN101 baseline/AdaBN step, 2 source + 2 "
@@ -384,7 +447,7 @@ def main():
         driver.calibrate_classifier(net, src[0][:1])          # logits std ~3 whatever the backbone's feature scale
     src = (src[0], driver.self_consistent_labels(net, src[0]))
 
-    schedule = {"fuse": not args.two_pass}
+    schedule = {"fuse": bool(args.fused) and not args.two_pass}
 
     def step(i):
         if baseline:      # train.py:274-289: source fwd/bwd/step + no-grad train-mode target forward (AdaBN)
@@ -444,6 +507,48 @@ def main():
             out_[k] = row
         return out_
 
+    def measure_with_device_views(first, steps):
+        """The same K steps with SURVEY 8f next-1 INSIDE the fences: per step and target image ONE u8 crop (+ label, padding mask)
+        crosses PCIe from pinned memory, `views.TargetViews.make` emits the L views on the device (flip / zoom / resize / blur /
+        jitter / greyscale / normalise / mask: dasac_make_views + dasac_view_photometric, the reference's Pillow pipeline of
+        dataloader_target.py:281-306) and `driver.prep_batch` slices them for this rank (train.py:157-209).  Returns
+        (ms per step, ms per step of the upload + view kernels alone by an event pair on the launch stream)."""
+        import views as V
+        tv = V.TargetViews(hw, args.views, seed=0, blur=(.1, 2.), jitter=0.4, jitter_p=0.5, grey_p=0.2)
+        mean = torch.tensor(V.MEAN).view(3, 1, 1)
+        std = torch.tensor(V.STD).view(3, 1, 1)
+        host = []
+        for gi in range(args.groups):       # u8 crops whose normalised form looks like the synthetic frames the other legs use
+            f = tgt[2][gi * args.views].detach().cpu()
+            img = ((f * std + mean) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous().pin_memory()
+            lab = tgt[1][gi * args.views].detach().cpu().clamp(0, 18).to(torch.uint8).contiguous().pin_memory()
+            msk = torch.zeros(hw, dtype=torch.uint8)
+            msk[:3] = 1
+            host.append((img, lab, msk.pin_memory()))
+        evs = []
+
+        def step_v(i):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            parts = [tv.make(*(t.to(dev, non_blocking=True) for t in h)) for h in host]
+            loaded = tuple(torch.stack([p[j] for p in parts], 0) for j in range(5))             # [N, L, ...] like the loader's batch
+            tgt_i = tuple(driver.prep_batch(t, args.groups, args.views) for t in loaded)
+            b.record()
+            evs.append((a, b))
+            return driver.sac_train_iteration(step_net, optim, src, tgt_i, args.views, update_teacher=False,
+                                              lr_target=cfg.LR_TARGET, fuse_passes=schedule["fuse"])
+
+        step_v(first)
+        fence()
+        evs.clear()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_v(first + 1 + i)
+        fence()
+        dt_ = time.perf_counter() - t0
+        views_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+        return dt_ / steps * 1e3, views_ms
+
     ops.set_precision(args.precision)
     per_rank = []
     # 1) the headline: K steps, nothing but the step itself inside the timed region
@@ -465,6 +570,17 @@ def main():
         except Exception as exc:
             other_sched = repr(exc)[:200]
         schedule["fuse"] = not schedule["fuse"]
+        done += 1 + args.steps
+    # 3b) the headline schedule once more with the target views generated ON THE DEVICE inside the timed region (N = 1)
+    with_views = None
+    if world == 1 and not baseline and args.config == "cfg3" and not args.no_kernel_table:
+        try:
+            ms_v, ms_views_only = measure_with_device_views(done, args.steps)
+            with_views = {"ms_per_step": round(ms_v, 3), "views_ms_per_step": round(ms_views_only, 3),
+                          "per_step": "{} u8 crops {}x{} (+ label, mask) H2D from pinned memory, {} views each on the device (zoom / flip / "
+                                      "blur / jitter p=.5 / greyscale p=.2), prep_batch".format(args.groups, hw[0], hw[1], args.views)}
+        except Exception as exc:
+            with_views = {"error": repr(exc)[:200]}
         done += 1 + args.steps
     fused_now = bool(schedule["fuse"]) and not baseline and wrapper != "ddp" and \
         net.backbone._batch_fits(args.batch + args.groups * args.views, hw[0], hw[1])     # else the driver runs the two passes
@@ -518,7 +634,7 @@ def main():
                        "parallelism": "dp{}".format(world),
                        "student_schedule": ("fused: source + target crops in ONE student pass and ONE backward over loss_ce + LR_TARGET*self_ce "
                                             "(same weights, frozen BN, teacher independent: the gradient sum of train.py:266-298's two passes)"
-                                            if fused_now else "two passes (train.py:266-298 call order)"),
+                                            if fused_now else "two passes: the module API as train.py calls it (train.py:128-133,219-233)"),
                        "distributed": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                                        "backend": dist.get_backend() if dist.is_initialized() else None, "wrapper": wrapper,
                                        "ranks_per_gpu": per_gpu, "self_launched": os.environ.get("DASAC_BENCH_SELF_LAUNCHED") == "1",
@@ -539,10 +655,15 @@ def main():
                          "measured_in": "second pass of {} steps with a HIP event pair around each launch (not the headline's timed region)".format(psteps)},
             "ms_per_step_instrumented": None if dt_prof is None else round(dt_prof / psteps * 1e3, 3),
             "ms_per_step_other_schedule": {("two_pass" if fused_now else "fused"): other_sched},
-            # the module API exactly as train.py calls it -- net(image, masks) then net(frames1, ..., use_teacher=True), two
-            # backward passes (train.py:128,219-222) -- over the same number of steps as `value` (which is the fused schedule)
+            # `value` is the module API exactly as train.py calls it unless --fused was given; both figures are always in the line:
+            # value_train_py_api = net(image, masks) + backward, then net(frames1, ..., use_teacher=True) + backward (train.py:128-133,
+            # 219-233); value_fused_schedule = SAC.forward_fused, one student pass + one backward over the same gradient sum
             "value_train_py_api": (round(world * args.batch / other_sched * 1e3, 4) if isinstance(other_sched, float) else None)
             if fused_now else round(world * args.batch * args.steps / dt, 4),
+            "value_fused_schedule": round(world * args.batch * args.steps / dt, 4) if fused_now
+            else (round(world * args.batch / other_sched * 1e3, 4) if isinstance(other_sched, float) else None),
+            "ms_per_step_with_device_views": None if with_views is None else with_views.get("ms_per_step"),
+            "device_views": with_views,
             "kernels": kernel_table(prof, psteps),
             "check": {"loss_ce": losses.get("loss_ce"), "self_ce": losses.get("self_ce"), "teacher_diff": losses.get("teacher_diff"),
                       "labelled_frac": round(labelled, 4)},
@@ -571,6 +692,14 @@ def main():
                 line["parity_fullres_head"] = dict(hcmp, oracle_seconds=round(hdt, 1))
             except Exception as exc:
                 line["parity_fullres_head"] = {"error": repr(exc)[:200]}
+            try:      # the reference's Pillow view pipeline for the same images, one host thread (the loader bottleneck next-1 removes)
+                one = pillow_views_ms(hw, args.views)
+                line["cpu_views_pillow"] = {"ms_per_target_image": round(one, 1), "ms_per_step": round(one * args.groups, 1), "threads": 1,
+                                            "what": "Pillow {}: per view flip / crop+resize (image BILINEAR, label+mask NEAREST) / GaussianBlur / "
+                                                    "jitter / greyscale / ToTensor+Normalize x2, {} views of one {}x{} crop".format(
+                                                        __import__("PIL").__version__, args.views, hw[0], hw[1])}
+            except Exception as exc:
+                line["cpu_views_pillow"] = {"error": repr(exc)[:160]}
             if not args.no_other_configs:
                 line["other_configs"] = {}
                 for name in ("cfg2", "cfg5"):

@@ -1459,12 +1459,6 @@ static bool persistent_grid_fits() {
   return ok;
 }
 
-// (experiment switch of round 6, removed once the A/B is recorded)
-static bool tail_enabled() {
-  static const int on = getenv("DASAC_TAIL") ? atoi(getenv("DASAC_TAIL")) : 1;
-  return on != 0;
-}
-
 // workers of a persistent stream-K launch: 3 per CU on the CUs this process does not leave to overlapped collectives.  `reserved` is
 // read ONCE per launch decision (reserved_cus()) and handed through: a concurrent dasac_set_reserved_cus must not make the
 // eligibility test, the schedule choice and the grid size of one launch disagree.
@@ -1522,7 +1516,7 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
   if constexpr (BM == 128 && BITS != 3) {
     const bool whole = g.n_tile0 == 0 && (long long)n_tiles * BN >= g.Npix;
     int lead_n = 0;
-    const int split = (schedule == 0 && whole && workspace && persistent_grid_fits() && tail_enabled()) ? tail_plan(m_tiles, n_tiles, g.Kpad / BK, reserved, lead_n) : 0;
+    const int split = (schedule == 0 && whole && workspace && persistent_grid_fits()) ? tail_plan(m_tiles, n_tiles, g.Kpad / BK, reserved, lead_n) : 0;
     if (split > 0) {
       if (ws_bytes < need) return fail(DASAC_EWORKSPACE, "conv_gemm: workspace too small (%zu < %zu)", ws_bytes, need);
       const int R = (n_tiles - lead_n) * m_tiles;
@@ -1621,25 +1615,11 @@ extern "C" int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K) {
   return want_streamk(tiles, (K + kBK - 1) / kBK, reserved_cus()) ? 1 : 0;
 }
 
-// Long-K convs whose tile count does not fill whole rounds of resident blocks are best issued as TWO launches:
-// the leading whole rounds one block per tile (blocks of a round run in lockstep over K, so neighbouring pixel tiles
-// share their halo rows in L2: measured 0.13 GB instead of 1.0 GB of HBM reads on the layer3 3x3) and only the
-// remainder on the persistent stream-K schedule.  Returns the pixel count of the leading launch, 0 = do not split.
-extern "C" int dasac_conv_gemm_plan(int Nb, int OH, int OW, int M, int K) {
-  const int Mpad = dasac_conv_mpad(M);
-  if (pick_bm(Mpad) != 128) return 0;
-  const int m_tiles = (M + 127) / 128, n_tiles = (Nb * OH * OW + 127) / 128, k_steps = (K + kBK - 1) / kBK;
-  const int tiles = m_tiles * n_tiles;
-  const int slots = kNumCu * 4;                                  // resident blocks of the tile-per-block kernel
-  // (Round 4, measured and rejected: extending this split to the short-K layers -- 16 <= K-steps < 64, many whole rounds plus a last
-  // one filled below half -- moves 59 more launches per cfg-3 step to stream-K: one block per tile 248.5 -> 246.9 ms, stream-K
-  // 28.9 -> 32.6 ms.  A remainder launch costs its ~25 us of ramp and hand-off whatever it saves of a thin last round.)
-  if (!want_streamk(tiles, k_steps, reserved_cus())) return 0;
-  const int lead = (tiles / slots) * slots / m_tiles;            // pixel tiles of the leading whole rounds
-  if (lead == 0 || lead >= n_tiles) return 0;
-  return lead * 128;
-}
-
+// (Rounds 2-5 issued a long-K conv whose tile count leaves a ragged last round as TWO launches -- whole rounds one block per tile,
+// the remainder on the persistent stream-K schedule (dasac_conv_gemm_plan) -- so that the lockstep K walk of the leading rounds
+// keeps sharing halo rows in L2.  Round 6 folded the remainder into the first launch: tail_plan / conv_gemm<SK = 2> above.
+// Measured on one box, cfg-3 fused step: GEMM kernel time 273.5 -> 272.6 ms, 169 launches per step gone; a piece's prologue and
+// deposit / epilogue cost what the second launch's ramp and hand-off did: profiles/r6_tail_and_qtap_ab.txt.)
 extern "C" size_t dasac_conv_gemm_workspace(void) {
   return (size_t)(kTailSlots > kSkWorkers ? kTailSlots : kSkWorkers) * 128 * 128 * sizeof(float) + (size_t)(kTailSlots + 1) * sizeof(int);
 }
@@ -1648,7 +1628,7 @@ extern "C" size_t dasac_conv_gemm_workspace(void) {
 // rounds of tile-per-block workgroups + a split-K tail; 0 = it does not (then dasac_conv_gemm_schedule tells the rest)
 extern "C" int dasac_conv_gemm_tail_split(int Nb, int OH, int OW, int M, int K) {
   const int Mpad = dasac_conv_mpad(M);
-  if (pick_bm(Mpad) != 128 || !persistent_grid_fits() || !tail_enabled()) return 0;
+  if (pick_bm(Mpad) != 128 || !persistent_grid_fits()) return 0;
   int lead_n = 0;
   return tail_plan((M + 127) / 128, (int)(((int64_t)Nb * OH * OW + 127) / 128), (K + kBK - 1) / kBK, reserved_cus(), lead_n);
 }

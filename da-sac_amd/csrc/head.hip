@@ -1153,7 +1153,11 @@ __global__ void class_state(float* __restrict__ chi, const double* __restrict__ 
     v = v + (1.f - momentum) * avg;
     chi[c] = v;
   }
-  if (disc) disc[c] = 1.f - expf(-(v / beta));
+  // exp correctly rounded to fp32 through the fp64 library (19 lanes: free).  NOT guaranteed bit-equal to the reference's CPU ATen
+  // (Sleef's 1-ULP expf for full vectors, libm's for vector tails -- which of the 19 classes take which depends on the host's
+  // vector width): the module's default evaluates these vectors on the host for that reason (ops.HostClassVectors); this output
+  // serves `SAC.device_thresholds = True` (no host round trip in the step; thresholds within 1 ULP of the host's).
+  if (disc) disc[c] = 1.f - (float)exp((double)(-(v / beta)));
   if (focal) {
     const float base = 1.f - fmaxf(v, 0.f);
     float r;

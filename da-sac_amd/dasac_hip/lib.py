@@ -29,7 +29,6 @@ PROTOTYPES = {
     "dasac_conv_pack_x3": (_i, [_p, _i, _i, _p, _p]),
     "dasac_conv_gemm_workspace": (_sz, []),
     "dasac_conv_gemm_schedule": (_i, [_i, _i, _i, _i, _i]),
-    "dasac_conv_gemm_plan": (_i, [_i, _i, _i, _i, _i]),
     "dasac_conv_gemm_tail_split": (_i, [_i, _i, _i, _i, _i]),
     "dasac_conv_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "dasac_conv_wgrad": (_i, [_p, _p, _p] + [_i] * 9 + [_p, _sz, _p]),

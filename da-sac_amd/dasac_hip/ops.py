@@ -201,8 +201,9 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     """out[n,m,oh*os,ow*os] = epilogue(sum_k packed[k][m] * gather(x)); see dasac_conv_gemm.
     mask: fp32 activation (zero where <= 0) or a ReluBits of the output's shape; bits_out: ReluBits to fill (relu only);
     stats: `tile_stats_buffer` to fill with per-tile channel sums / sums of squares of the output (dasac_conv_gemm_stats).
-    schedule: None = the library's choice (M-sweep kernel for the short-K 1x1 layers, hybrid tile-per-block + stream-K for long-K
-    layers with a ragged last round, ...); 1 / 2 force one block per tile / the persistent stream-K kernel (tests, tools)."""
+    schedule: None = the library's choice (one block per tile; long-K layers with a ragged last round: whole rounds one block per
+    tile + a split-K tail in the same launch; few tiles x long K: the persistent stream-K kernel); 1 / 2 force one block per tile /
+    the persistent stream-K kernel (tests, tools)."""
     lib = L.load()
     L.require_gpu(x, packed, table, out)
     Nb, Cx, H, W = x.shape
@@ -243,18 +244,13 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     if schedule is not None:
         launch("conv_gemm<stream-K>" if schedule == 2 else "conv_gemm<tile-per-block>", 0, 0, int(schedule))
         return out
-    if stats is None and hasattr(lib, "dasac_conv_gemm_tail_split") and lib.dasac_conv_gemm_tail_split(Nb, OH, OW, M, K) > 0:
+    if stats is None and lib.dasac_conv_gemm_tail_split(Nb, OH, OW, M, K) > 0:
         # ONE launch: whole rounds one block per tile (lockstep over K: halo rows shared in L2) + the remaining tiles cut into
         # K-ranges that fill the chip once more (round 6; rounds 2-5 issued that remainder as a second, persistent stream-K launch)
         launch("conv_gemm<tile+tail>", 0, 0, 0)
         return out
-    lead = lib.dasac_conv_gemm_plan(Nb, OH, OW, M, K)
-    if lead > 0:        # whole rounds one block per tile (lockstep over K: halo rows shared in L2), the rest stream-K
-        launch("conv_gemm<tile-per-block>", 0, lead, 1)
-        launch("conv_gemm<stream-K>", lead, 0, 0)
-    else:
-        sk = PROFILE.on and lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K)
-        launch("conv_gemm<stream-K>" if sk else "conv_gemm<tile-per-block>", 0, 0, 0)
+    sk = PROFILE.on and lib.dasac_conv_gemm_schedule(Nb, OH, OW, M, K)
+    launch("conv_gemm<stream-K>" if sk else "conv_gemm<tile-per-block>", 0, 0, 0)
     return out
 
 
@@ -521,6 +517,19 @@ class HostClassVectors:
         vecs[1] = (1 - chi.clamp(0.)) ** focal_p
         dev = vecs.to(self.device, non_blocking=True)
         return (dev[0] if want_disc else None), dev[1]
+
+
+class DeviceClassVectors:
+    """The same two vectors from `dasac_class_state` on the device (exp through the fp64 library, rounded once): no copy to the
+    host, no synchronisation -- a step that uses them is one uninterrupted launch sequence.  Within 1 ULP of HostClassVectors,
+    not bit-equal to it by construction (see there), so pseudo labels can differ from the CPU reference's on a pixel whose
+    confidence equals a threshold to the last bit.  Opt-in: `SAC.device_thresholds = True`."""
+
+    def __init__(self, disc, focal):
+        self.disc, self.focal = disc, focal
+
+    def finish(self, beta, focal_p, want_disc=True):
+        return (self.disc if want_disc else None), self.focal
 
 
 def class_vectors(running_conf, beta, focal_p, want_disc=True):

@@ -77,31 +77,45 @@ def prep_batch(tensor, num_groups, group_size, rank=None, world=None, device=Non
     rank, world = _dist_state(rank, world)
     assert (num_groups * group_size) % world == 0, "Batch size does not fit world size"
     per = num_groups * group_size // world
-    if device is not None:
-        tensor = tensor.to(device, non_blocking=True)
     if per >= group_size:
+        if device is not None:
+            tensor = tensor.to(device, non_blocking=True)
         return tensor.flatten(0, 1)
     assert tensor.size(1) == group_size, "Loaded sequence is incorrect {} vs. {}".format(tensor.size(1), group_size)
+    # WHERE the exchange runs.  RCCL ("nccl") moves device tensors, stream-ordered: upload first, exchange on the device.  gloo
+    # is a host transport: its collectives stage device tensors through pinned memory, but its send / recv hand the tensor's
+    # data pointer to the TCP transport as it is -- with a device tensor the host reads (writes) VRAM through the PCIe BAR with
+    # no ordering against the stream that fills (consumes) it.  Found by the 8-rank one-device test of round 6 (ranks that are
+    # sender and receiver at once got torn slices).  With gloo the loader's HOST tensor is exchanged and only the `per` views
+    # this rank keeps cross PCIe afterwards.
+    host_exchange = dist.get_backend() == "gloo"
+    if device is not None and not host_exchange:
+        tensor = tensor.to(device, non_blocking=True)
+    if host_exchange and tensor.is_cuda:
+        tensor = tensor.cpu()
     first = rank * per
     owner, lo = first // group_size, first % group_size
     tensor = tensor.contiguous()
     if exchange == "all_gather":
         parts = [torch.empty_like(tensor) for _ in range(world)]
         dist.all_gather(parts, tensor)
-        return parts[owner].flatten(0, 1)[lo:lo + per]
-    assert exchange == "p2p", exchange
-    flat = tensor.flatten(0, 1)
-    mine = flat[lo:lo + per].clone() if owner == rank else torch.empty_like(flat[:per])
-    work = []
-    for dst in range(world):                    # what this rank owes the ranks whose slice lives here
-        if dst != rank and (dst * per) // group_size == rank:
-            d_lo = (dst * per) % group_size
-            work.append(dist.P2POp(dist.isend, flat[d_lo:d_lo + per].contiguous(), dst))
-    if owner != rank:
-        work.append(dist.P2POp(dist.irecv, mine, owner))
-    if work:
-        for req in dist.batch_isend_irecv(work):
-            req.wait()
+        mine = parts[owner].flatten(0, 1)[lo:lo + per]
+    else:
+        assert exchange == "p2p", exchange
+        flat = tensor.flatten(0, 1)
+        mine = flat[lo:lo + per].clone() if owner == rank else torch.empty_like(flat[:per])
+        work = []
+        for dst in range(world):                    # what this rank owes the ranks whose slice lives here
+            if dst != rank and (dst * per) // group_size == rank:
+                d_lo = (dst * per) % group_size
+                work.append(dist.P2POp(dist.isend, flat[d_lo:d_lo + per].contiguous(), dst))
+        if owner != rank:
+            work.append(dist.P2POp(dist.irecv, mine, owner))
+        if work:
+            for req in dist.batch_isend_irecv(work):
+                req.wait()
+    if device is not None and host_exchange:
+        mine = mine.to(device, non_blocking=True)
     return mine
 
 

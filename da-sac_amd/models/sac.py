@@ -52,6 +52,10 @@ class SAC(SAC_Baseline):
         self.register_buffer("slow_init", torch.Tensor([False]))
         self._ema_plan = None
         self._class_vectors = None
+        # False (default): per-class thresholds / focal weights are evaluated by the host's ATen kernels -- the reference's own
+        # arithmetic, label maps bit-equal on equal probabilities, one 19-float round trip per target step.  True: on the device in
+        # the class-prior kernel (within 1 ULP, no host synchronisation: see ops.DeviceClassVectors)
+        self.device_thresholds = False
         self._exempt_frozen_bn_buffers_from_ddp_broadcast()
 
     def _exempt_frozen_bn_buffers_from_ddp_broadcast(self):
@@ -199,10 +203,16 @@ class SAC(SAC_Baseline):
         B, _, h, w = frames.size()
         _, probs, sums = ops.upsample_softmax(pred_logits, (h, w), ignore_mask, want_up=False, want_probs=True,
                                               want_sums=self.training)
-        if self.training:
-            ops.class_state(self.running_conf, sums, B, h * w, self.cfg.THRESHOLD_BETA, self.cfg.STAT_MOMENTUM, True,
-                            self.cfg.FOCAL_P, want_disc=False, want_focal=False)
-        self._class_vectors = ops.HostClassVectors(self.running_conf)      # chi is final for this step: start its D2H
+        if self.device_thresholds:
+            # opt-in: threshold discount / focal weights from the SAME launch that updates chi -- no host round trip in the step
+            disc, fw = ops.class_state(self.running_conf, sums, B, h * w, self.cfg.THRESHOLD_BETA, self.cfg.STAT_MOMENTUM,
+                                       bool(self.training), self.cfg.FOCAL_P, want_disc=True, want_focal=True)
+            self._class_vectors = ops.DeviceClassVectors(disc, fw)
+        else:
+            if self.training:
+                ops.class_state(self.running_conf, sums, B, h * w, self.cfg.THRESHOLD_BETA, self.cfg.STAT_MOMENTUM, True,
+                                self.cfg.FOCAL_P, want_disc=False, want_focal=False)
+            self._class_vectors = ops.HostClassVectors(self.running_conf)      # chi is final for this step: start its D2H
         diags = {}
         if not pool:
             return probs, diags

@@ -152,8 +152,6 @@ int dasac_conv_gemm_stats(const float* x, const float* packed, const int32_t* ta
                           float* stats, dasac_stream_t stream);
 size_t dasac_conv_gemm_workspace(void);
 int dasac_conv_gemm_schedule(int Nb, int OH, int OW, int M, int K);   /* 1 = stream-K, 0 = one block per tile */
-/* > 0: issue the conv as two launches -- pixels [0, n) with schedule 1, the rest with schedule 0 (see conv_igemm.hip) */
-int dasac_conv_gemm_plan(int Nb, int OH, int OW, int M, int K);
 /* > 0: dasac_conv_gemm(schedule 0, the whole pixel range, workspace given) runs this shape as ONE launch -- the leading whole
  * rounds of resident workgroups one block per tile, the remaining tiles cut into that many K-ranges of one block each (split-K
  * tail: the later ranges deposit their accumulators in the workspace, the piece with the first K-steps adds them and runs

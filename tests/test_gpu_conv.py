@@ -333,7 +333,7 @@ def test_split_k_tail_in_the_tile_launch(cin, cout, k, dil, shape, want_split):
         b, bb = run(1, shift_, res_, relu, want_bits, mask_)
         a2, _ = run(None, shift_, res_, relu, want_bits, mask_)
         assert not torch.isnan(a).any()
-        assert rel_err(a, b) < 2e-6
+        assert rel_err(a, b) < 1e-5                           # fp32 sums of up to 4608 products in another order
         assert torch.equal(a, a2)
         assert float((a != b).float().mean()) < 0.5          # the leading rounds run the very same code: equal bits there
         if want_bits:

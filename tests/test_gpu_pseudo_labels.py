@@ -98,3 +98,48 @@ def test_labels_bit_equal_through_the_module_threshold_path(golden):
         assert torch.equal(lab.cpu(), ref_lab) and torch.equal(conf.cpu(), ref_conf), trial
         assert torch.equal(net._focal_weight(cfg.FOCAL_P).cpu(), H.focal_weight(chi, cfg.FOCAL_P))
         assert int((ref_lab != 255).sum()) > 0
+
+
+def test_device_thresholds_stay_within_one_ulp_of_the_host_path_and_need_no_host_copy():
+    """`SAC.device_thresholds = True` (round 6, opt-in): 1 - exp(-chi/beta) and (1 - chi)^p from the class-prior kernel itself
+    (fp64 exp rounded once) instead of the 19-float host round trip.  Not bit-equal to the host's ATen by construction (Sleef's
+    1-ULP expf for full vectors, libm for vector tails: which class takes which depends on the host's vector width), but
+    within one unit in the last place of exp(.) over a dense sweep of chi -- and a whole refinement + labelling pass then
+    issues no device-to-host copy."""
+    from types import SimpleNamespace as NS
+    import torch.nn as nn
+    import models
+    from dasac_hip import ops
+    from oracle.step_ref import DEFAULT_CFG
+    cfg = NS(**dict(DEFAULT_CFG, INIT_MODEL="", OPT_NESTEROV=False))
+    beta = cfg.THRESHOLD_BETA
+    gen = torch.Generator().manual_seed(9)
+    worst = 0.0
+    for scale in (2e-3, 2e-2, 1.0):                        # chi around beta (where the discount moves) and up to 1
+        for _ in range(64):
+            chi = (torch.rand(19, generator=gen) * scale).cuda()
+            disc_d, fw_d = ops.class_state(chi.clone(), None, 1, 1, beta, cfg.STAT_MOMENTUM, False, cfg.FOCAL_P, want_disc=True, want_focal=True)
+            disc_h, fw_h = ops.class_vectors(chi, beta, cfg.FOCAL_P)
+            e_h = torch.exp(-chi.cpu() / beta)
+            ulp = torch.maximum(e_h.abs() * 2.0 ** -23, torch.tensor(2.0 ** -149))
+            worst = max(worst, float(((disc_d.cpu() - disc_h.cpu()).abs() / torch.maximum(ulp, torch.tensor(2.0 ** -24))).max()))
+            assert torch.equal(fw_d.cpu(), fw_h.cpu())      # (1 - chi)^3 is two fp32 multiplications on both sides
+    assert worst <= 1.0, worst
+    # the module path: same labels up to threshold ties, and no D2H copy while refining + labelling
+    net = models.get_model(cfg, 0, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none")).cuda().train()
+    probs_logits = (torch.randn(4, 19, 13, 17, generator=gen) * 3).cuda()
+    frames = torch.randn(4, 3, 97, 129, generator=gen).cuda()
+    import driver
+    theta, inv = driver.view_affines(driver.BENCH_VIEWS, 97, 129)
+    ignore = (torch.rand(4, 97, 129, generator=gen) < 0.05).cuda()
+    out = {}
+    for dev_thr in (False, True):
+        net.device_thresholds = dev_thr
+        net.running_conf.fill_(0.05)
+        refined, _ = net._refine(frames, probs_logits, 4, theta.cuda(), inv.cuda(), ignore, pool=True)
+        disc, fw = net._class_vectors.finish(beta, cfg.FOCAL_P, True)
+        lab, conf, _ = ops.pseudo_labels(refined, ignore, cfg.RUN_CONF_UPPER, cfg.RUN_CONF_LOWER, disc)
+        out[dev_thr] = (lab.cpu(), conf.cpu(), disc.cpu())
+        assert isinstance(net._class_vectors, ops.DeviceClassVectors if dev_thr else ops.HostClassVectors)
+    assert float((out[True][0] != out[False][0]).float().mean()) < 1e-5 and int((out[True][0] != 255).sum()) > 0
+    assert float((out[True][2] - out[False][2]).abs().max()) <= 2.0 ** -23

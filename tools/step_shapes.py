@@ -1,5 +1,6 @@
 """Per-shape breakdown of the GEMM kernels inside one cfg-3 step (which layers the time goes to).
-Usage (GPU box): python tools/step_shapes.py [steps]  ->  table sorted by time."""
+Usage (GPU box): python tools/step_shapes.py [steps] [two|fused]  ->  table sorted by time (default: the two-call train.py order,
+the bench headline since round 6; "fused" = SAC.forward_fused)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +12,7 @@ from dasac_hip import ops
 from models import get_model
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+FUSE = len(sys.argv) > 2 and sys.argv[2] == "fused"
 dev = torch.device("cuda:0")
 cfg = bench.model_cfg("deeplabv2_resnet101", False)
 sys.stdout, out = open(os.devnull, "w"), sys.stdout
@@ -26,7 +28,7 @@ sys.stdout = out
 
 def step(i):
     tgt_i = (tgt[0], tgt[1].clone(), tgt[2], tgt[3], tgt[4])
-    return driver.sac_train_iteration(net, opt, src, tgt_i, 4, update_teacher=(i == 0), lr_target=cfg.LR_TARGET, fuse_passes=True)
+    return driver.sac_train_iteration(net, opt, src, tgt_i, 4, update_teacher=(i == 0), lr_target=cfg.LR_TARGET, fuse_passes=FUSE)
 
 
 step(0)
