@@ -582,6 +582,18 @@ def main():
         except Exception as exc:
             with_views = {"error": repr(exc)[:200]}
         done += 1 + args.steps
+    # 3c) what the one host round trip of a target step costs: the same steps with thresholds / focal weights from the device
+    #     (SAC.device_thresholds: within 1 ULP of the host's ATen values, not bit-equal to them -- the default stays the host path)
+    dev_thr_ms = None
+    if world == 1 and not baseline and not args.no_kernel_table and hasattr(net, "device_thresholds"):
+        net.device_thresholds = True
+        try:
+            dt4, _, _ = measure(done, 1, args.steps, False)
+            dev_thr_ms = round(dt4 / args.steps * 1e3, 3)
+        except Exception as exc:
+            dev_thr_ms = repr(exc)[:200]
+        net.device_thresholds = False
+        done += 1 + args.steps
     fused_now = bool(schedule["fuse"]) and not baseline and wrapper != "ddp" and \
         net.backbone._batch_fits(args.batch + args.groups * args.views, hw[0], hw[1])     # else the driver runs the two passes
     alt = None
@@ -662,6 +674,7 @@ def main():
             if fused_now else round(world * args.batch * args.steps / dt, 4),
             "value_fused_schedule": round(world * args.batch * args.steps / dt, 4) if fused_now
             else (round(world * args.batch / other_sched * 1e3, 4) if isinstance(other_sched, float) else None),
+            "ms_per_step_device_thresholds": dev_thr_ms,
             "ms_per_step_with_device_views": None if with_views is None else with_views.get("ms_per_step"),
             "device_views": with_views,
             "kernels": kernel_table(prof, psteps),

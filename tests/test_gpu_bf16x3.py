@@ -60,7 +60,9 @@ def test_conv_bf16x3_matches_fp32_kernel(case, bf16x3):
         assert rel_err(out["bf16x3"][1], out["fp32"][1]) < 3e-5
     for a, b in zip(out["bf16x3"][2], out["fp32"][2]):
         assert rel_err(a, b) < 3e-5
-    assert torch.equal(out["bf16x3"][3], out["fp32"][3])            # channel sums of dz stay exact fp32 adds
+    # channel sums of dz stay fp32 adds in both modes; the fp32 mode's quad loader (1x1 and, since round 6, "same"-padded 3x3
+    # layers) adds them in another order than the dword loader the split-bf16 kernel keeps
+    assert rel_err(out["bf16x3"][3], out["fp32"][3]) < 1e-6
     # and against ATen in float64 (forward)
     ref = sum(nn.functional.conv2d(x.double().cpu(), w.double().cpu(), stride=stride, padding=b[3], dilation=b[2])
               for w, b in zip(ws, br))

@@ -24,7 +24,9 @@ def klass(name):
     m = re.match(r"dasac::conv_gemm<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(1).split(",")]
-        return "conv_gemm<stream-K>" if args[5] == "true" else "conv_gemm<tile-per-block>"
+        # template argument 6 = SK: 0 one block per tile, 1 persistent stream-K, 2 tile-per-block rounds + split-K tail (round 6;
+        # rounds 1-5: a bool)
+        return {"1": "conv_gemm<stream-K>", "true": "conv_gemm<stream-K>", "2": "conv_gemm<tile+tail>"}.get(args[5], "conv_gemm<tile-per-block>")
     if name.startswith("dasac::conv_wgrad<"):
         return "conv_wgrad"
     return None
