@@ -6,7 +6,7 @@
 #   gpurun_out/<tag>/hbm_traffic.md        FETCH_SIZE / WRITE_SIZE per launch (two separate --pmc passes)
 # Copy what should be judged into profiles/ afterwards.  PMC passes carry --kernel-trace only (no sys/hip traces).
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
