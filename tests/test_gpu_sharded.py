@@ -35,7 +35,9 @@ ARCHS = {
 # the other moves it.  With 8 ranks x 3 crops x 2 passes x 2 iterations 2.4 M such units exist and ~2 of them are borderline at 1e-6
 # (measured: 2.9e-3 of max on all ranks alike, deterministic; the oracle in fp32 and in fp64 agree to 4e-7 on this tensor, so the
 # oracle side has no flip).  The effect and its fp64 arbitration: tests/test_gpu_models.py::test_resnet101_gradients_fp64_arbitration.
-PARAM_TOL = {"vgg_head.4.bias": 2e-2}
+# `vgg_head.8.bias` (the classifier's bias, also zero at the start: a gradient comparison, downstream of the same units) gets the
+# contract's 1e-3 (measured 2.2e-4 at 8 ranks); parameters that start at their trained-scale values keep 2e-4.
+PARAM_TOL = {"vgg_head.4.bias": 2e-2, "vgg_head.8.bias": 1e-3}
 SRC_B, ITERS = 2, 2
 # (arch, world, N target images, L views per image): per = N*L/world views per rank < L in every case
 CASES = [("deeplabv2_resnet101", 2, 1, 2), ("fcn_vgg16_bn", 2, 1, 2), ("deeplabv2_resnet101", 4, 1, 4),
