@@ -1485,14 +1485,21 @@ static int tail_plan(int m_tiles, int n_tiles, int k_steps, int reserved, int& l
   const int tiles = m_tiles * n_tiles;
   if (!want_streamk(tiles, k_steps, reserved)) return 0;
   lead_n = (tiles / kTileSlots) * kTileSlots / m_tiles;          // pixel tiles of the leading whole rounds
+  // (fewer tiles than resident blocks -- small batches, cfg-2's 296 tiles -- stay on the persistent kernel: the same launches as pure
+  // split-K pieces of this kernel, 4 blocks per CU, measured 35.4 against 33.9 ms per cfg-2 step: equal ranges balance better than
+  // equal pieces when nothing leads; profiles/EXPERIMENTS.md round 6)
   if (lead_n <= 0 || lead_n >= n_tiles) return 0;
   const int R = (n_tiles - lead_n) * m_tiles;
   int best = 0;
   double best_cost = 0.0;
-  for (int sp = 1; sp <= 8 && sp * 8 <= k_steps; ++sp) {
+  // (a sweep of the minimum piece length 8 .. 32 K-steps and of the fixed cost 6 .. 20 moved the three tail shapes of the step by
+  // less than 1 %: tools/experiments/r6_tail_sweep.sh, EXPERIMENTS.md)
+  constexpr int min_steps = 8;
+  constexpr double ovh = 6.0;
+  for (int sp = 1; sp <= 8 && sp * min_steps <= k_steps; ++sp) {
     if ((long long)R * (sp - 1) > kTailSlots) break;
     const int rounds = (R * sp + kTileSlots - 1) / kTileSlots;
-    const double cost = rounds * ((double)k_steps / sp + 6.0);
+    const double cost = rounds * ((double)k_steps / sp + ovh);
     if (best == 0 || cost < best_cost - 1e-9) {
       best = sp;
       best_cost = cost;
@@ -1513,7 +1520,7 @@ static int launch_gemm(const float* X, const float* Wp, const int4* tab, float* 
   const size_t need = part_bytes + (size_t)(kTailSlots + 1) * sizeof(int);
   float* partial = reinterpret_cast<float*>(workspace);
   int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + part_bytes);
-  if constexpr (BM == 128 && BITS != 3) {
+  if constexpr (BM == 128) {
     const bool whole = g.n_tile0 == 0 && (long long)n_tiles * BN >= g.Npix;
     int lead_n = 0;
     const int split = (schedule == 0 && whole && workspace && persistent_grid_fits()) ? tail_plan(m_tiles, n_tiles, g.Kpad / BK, reserved, lead_n) : 0;

@@ -244,7 +244,7 @@ def conv_gemm(x, packed, table, out, grid_hw, stride, M, K, ostride=1, shift=Non
     if schedule is not None:
         launch("conv_gemm<stream-K>" if schedule == 2 else "conv_gemm<tile-per-block>", 0, 0, int(schedule))
         return out
-    if stats is None and lib.dasac_conv_gemm_tail_split(Nb, OH, OW, M, K) > 0:
+    if lib.dasac_conv_gemm_tail_split(Nb, OH, OW, M, K) > 0:
         # ONE launch: whole rounds one block per tile (lockstep over K: halo rows shared in L2) + the remaining tiles cut into
         # K-ranges that fill the chip once more (round 6; rounds 2-5 issued that remainder as a second, persistent stream-K launch)
         launch("conv_gemm<tile+tail>", 0, 0, 0)
