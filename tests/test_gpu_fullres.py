@@ -259,3 +259,48 @@ def test_cfg5_full_batch_fused_student_pass_equals_the_two_passes():
     assert torch.equal(laba, labb)                      # the teacher does not depend on the student schedule
     worst = max(float((pa[k] - pb[k]).abs().max() / pb[k].abs().max().clamp_min(1e-30)) for k in pb)
     assert worst <= 1e-4, worst
+
+
+def test_split_k_tail_schedule_inside_the_network_equals_one_block_per_tile():
+    """Round 6: at cfg-3's per-pass size (8 crops of 769 x 769) every long-K layer of ResNet-101 runs as ONE launch of tile-per-block
+    rounds + split-K tail pieces.  The whole student pass (forward, loss, backward) under the library's schedule against the same pass
+    with every GEMM forced to one block per tile: the same arithmetic up to the summation order of the cut tiles -- logits and loss to
+    1e-5 / 1e-6, gradients to 1e-4 of the tensor max for the median tensor (single tensors upstream of a ReLU unit whose pre-activation
+    is within rounding of zero move more: the effect tests/test_gpu_models.py arbitrates in float64)."""
+    import torch
+    import torch.nn as nn
+    sys.path.insert(0, ROOT)
+    import bench
+    import driver
+    import models
+    from dasac_hip import ops
+    cfg = bench.model_cfg()
+    net = models.get_model(cfg, 0, num_classes=19, criterion=nn.CrossEntropyLoss(ignore_index=255, reduction="none"))
+    driver.init_synthetic_weights(net, seed=0)
+    net.cuda().train()
+    (x, y), _ = driver.synthetic_batches(8, 1, 1, (769, 769), "cuda", seed=0)
+    real = ops.conv_gemm
+
+    def run(force_tile_per_block):
+        if force_tile_per_block:
+            ops.conv_gemm = lambda *a, **k: real(*a, **dict(k, schedule=1))
+        try:
+            ops.PROFILE.start()
+            losses, outs = net.backbone(x, y)
+            for p in net.backbone.parameters():
+                p.grad = None
+            losses["loss_ce"].mean().backward()
+            prof = ops.PROFILE.stop()
+        finally:
+            ops.conv_gemm = real
+        torch.cuda.synchronize()
+        return (outs["logits"].detach().clone(), float(losses["loss_ce"]),
+                {n: p.grad.detach().clone() for n, p in net.backbone.named_parameters() if p.grad is not None}, prof)
+
+    lg_a, loss_a, g_a, prof_a = run(False)
+    lg_b, loss_b, g_b, prof_b = run(True)
+    assert prof_a["conv_gemm<tile+tail>"]["launches"] >= 100 and "conv_gemm<tile+tail>" not in prof_b
+    assert _tmax(lg_a, lg_b) < 1e-5 and abs(loss_a - loss_b) <= 1e-6 * abs(loss_b)
+    errs = sorted(_tmax(g_a[k], g_b[k]) for k in g_a)
+    print("tail vs tile-per-block, 320 gradients: median %.2e, 95%% %.2e, max %.2e" % (errs[len(errs) // 2], errs[int(len(errs) * 0.95)], errs[-1]))
+    assert len(errs) == 320 and errs[len(errs) // 2] < 1e-4 and errs[-1] < 5e-2
