@@ -90,8 +90,12 @@ int dasac_pseudo_labels(const float* probs, const uint8_t* ignore, const float* 
  *                    output pixels [pix_begin, pix_begin + pix_count) of the flattened (n, oh, ow) grid
  *                    (whole 128-pixel tiles; pix_count 0 = to the end); schedule 0 = pick, 1 = one block
  *                    per tile, 2 = persistent stream-K.  With a workspace of
- *                    dasac_conv_gemm_workspace() bytes the launcher may pick the persistent stream-K
- *                    schedule (equal matrix work per CU); workspace NULL = one block per tile.
+ *                    dasac_conv_gemm_workspace() bytes (129 MB) schedule 0 may pick, for a long contraction whose
+ *                    tile count leaves a ragged last round of resident workgroups: over the whole pixel range, ONE
+ *                    launch of the leading whole rounds one block per tile + the remaining tiles cut into K-ranges
+ *                    (split-K tail, dasac_conv_gemm_tail_split); with fewer tiles than resident workgroups, the
+ *                    persistent stream-K schedule (equal matrix work per CU).  workspace NULL = one block per tile.
+ *                    Every choice is a function of the shape and dasac_reserved_cus() alone: run-to-run identical bits.
  *                    The workspace must be ZERO-FILLED by the caller when it is allocated and belong to one
  *                    stream at a time: its hand-off flags are self-cleaning (every launch leaves them
  *                    zero), which saves a memset per launch.
