@@ -303,4 +303,4 @@ def test_split_k_tail_schedule_inside_the_network_equals_one_block_per_tile():
     assert _tmax(lg_a, lg_b) < 1e-5 and abs(loss_a - loss_b) <= 1e-6 * abs(loss_b)
     errs = sorted(_tmax(g_a[k], g_b[k]) for k in g_a)
     print("tail vs tile-per-block, 320 gradients: median %.2e, 95%% %.2e, max %.2e" % (errs[len(errs) // 2], errs[int(len(errs) * 0.95)], errs[-1]))
-    assert len(errs) == 320 and errs[len(errs) // 2] < 1e-4 and errs[-1] < 5e-2
+    assert len(errs) == 320 and errs[len(errs) // 2] < 5e-5 and errs[-1] < 1e-3         # measured: median 8.3e-6, max 7.9e-5
