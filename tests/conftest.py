@@ -68,3 +68,43 @@ def init_ranks(rank, world):
     kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return dev
+
+
+def run_ranks(target, world, make_args, timeout=300, attempts=2):
+    """Spawns `world` rank processes (`target(*make_args(rank, port, queue))`), collects one queue item per rank and returns them
+    sorted by rank.  Bounded: a rank that dies or hangs costs `timeout` seconds, not the suite's budget.  A rank PROCESS failure (crash,
+    non-zero exit, nothing on the queue in time) is retried once with fresh processes and a fresh port -- round 6 saw one
+    `HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION` queue abort in an 8-processes-on-one-device run that two reruns did not reproduce
+    (profiles/ROUND6.md).  Numerical assertions are the caller's and are never retried."""
+    import queue as _queue
+    import socket
+    import sys
+    import torch.multiprocessing as mp
+    last = None
+    for attempt in range(attempts):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=target, args=make_args(r, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = []
+        try:
+            for _ in procs:
+                got.append(q.get(timeout=timeout))
+        except _queue.Empty:
+            last = "only {} of {} ranks reported within {} s".format(len(got), world, timeout)
+        for p in procs:
+            p.join(60 if len(got) == world else 5)
+            if p.is_alive():
+                p.kill()              # the exact processes this call started
+                p.join(10)
+        codes = [p.exitcode for p in procs]
+        if len(got) == world and all(c == 0 for c in codes):
+            return sorted(got, key=lambda t: t[0])
+        last = "{}; exit codes {}".format(last or "ranks exited abnormally", codes)
+        print("run_ranks: attempt {} failed ({}){}".format(attempt + 1, last, "; retrying" if attempt + 1 < attempts else ""), file=sys.stderr)
+    raise AssertionError("rank processes failed {} times: {}".format(attempts, last))

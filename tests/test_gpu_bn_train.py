@@ -167,7 +167,7 @@ def test_syncbn_two_ranks_match_one_process_on_the_concatenated_batch():
     xs, ys, xt = (torch.cat([a, b], 0) for a, b in zip(d0, d1))
     ref = SacOracle(sd, cfg=dict(BASELINE=True))
     l_ref = baseline_train_iteration(ref, SgdOracle(ref), (xs, ys), xt)
-    got = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
+    got = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
     for p_ in procs:
         p_.join(120)
         assert p_.exitcode == 0

@@ -112,7 +112,7 @@ def test_ddp_two_ranks_average_gradients_like_a_manual_mean():
     procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    got = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
     got = [(r, l, {k: torch.from_numpy(v) for k, v in w.items()}) for r, l, w in got]
     for p in procs:
         p.join(120)

@@ -88,7 +88,7 @@ def test_bench_launches_its_own_ranks(ranks, size):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--size", str(size),
            "--batch", "2", "--groups", "1", "--views", "2", "--profile-steps", "1"]
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines

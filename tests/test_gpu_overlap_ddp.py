@@ -153,22 +153,8 @@ def _rank_main(rank, world, port, q, use_torch_ddp):
 
 
 def _spawn(use_torch_ddp, world=2):
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, use_torch_ddp)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = sorted((q.get(timeout=420) for _ in procs), key=lambda t: t[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    return got
+    from conftest import run_ranks
+    return run_ranks(_rank_main, world, lambda r, port, q: (r, world, port, q, use_torch_ddp), timeout=240)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

@@ -128,22 +128,15 @@ def _oracle(case):
 
 @pytest.mark.parametrize("case", CASES, ids=["{}-world{}-N{}-L{}".format(*c) for c in CASES])
 def test_view_sharded_sac_iterations_vs_oracle(case):
-    import torch.multiprocessing as mp
+    import threading
+    from conftest import run_ranks
     arch, WORLD, GROUPS, VIEWS = case
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, port, case, q)) for r in range(WORLD)]
-    for p in procs:
-        p.start()
-    ref = _oracle(case)                                     # the CPU oracle runs while the GPU ranks do
-    got = sorted((q.get(timeout=1500) for _ in procs), key=lambda t: t[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    ref = {}
+    th = threading.Thread(target=lambda: ref.update(out=_oracle(case)))       # the CPU oracle runs while the GPU ranks do
+    th.start()
+    got = run_ranks(_rank_main, WORLD, lambda r, port, q: (r, port, case, q), timeout=300)
+    th.join()
+    ref = ref["out"]
     fired = 0
     bad = []          # every violated bound of every (rank, iteration): a failure shows the whole picture, not the first symptom
 
