@@ -17,19 +17,32 @@ def rank_main(rank, port, case, q):
 
     def wrapped(self, update=False):
         out = real(self, update)
+        if self._ema_plan is None:
+            return out
+        plan = self._ema_plan[1]
         fast, slow = self._ema_pairs()
-        with torch.no_grad():
-            ref = sum(float((s.double() - f.double()).norm()) for f, s in zip(fast, slow))
-            cs = (float(sum(f.double().sum() for f in fast)), float(sum(s.double().sum() for s in slow)))
-        log.append((bool(update), float(out), ref, cs))
+        with torch.no_grad():          # everything stays on the stream: no host read here (the first version's float() hid the flake)
+            per_kernel = plan.sq[:plan.n_tensors].clone()
+            per_torch = torch.stack([(s_.double() - f.double()).pow(2).sum() for f, s_ in zip(fast, slow)])
+        log.append((bool(update), out, per_kernel, per_torch))
         return out
     sac_mod.SAC._momentum_update = wrapped
     import test_gpu_sharded as T
 
     class Q:
         def put(self, item):
-            q.put((item[0], [(r["teacher_diff"]) for r in item[1]], log))
+            names = [k for k in net_keys(sac_mod) ]
+            rows = []
+            for upd, out, pk, pt in log:
+                pk, pt = pk.cpu(), pt.cpu()
+                bad = [(i, float(pk[i]), float(pt[i])) for i in range(pk.numel()) if abs(float(pk[i]) - float(pt[i])) > 1e-6 * max(float(pt[i]), 1e-30)]
+                rows.append((upd, float(out), float(pk.sqrt().sum()), float(pt.sqrt().sum()), bad[:6]))
+            q.put((item[0], [r["teacher_diff"] for r in item[1]], rows))
     T._rank_main(rank, port, case, Q())
+
+
+def net_keys(_):
+    return []
 
 
 if __name__ == "__main__":
@@ -38,10 +51,7 @@ if __name__ == "__main__":
     case = ("fcn_vgg16_bn", 8, 2, 4)
     for rep in range(reps):
         got = run_ranks(rank_main, 8, lambda r, port, q: (r, port, case, q), timeout=300)
-        ref = got[0][2]
-        for r, tds, log in got:
-            flag = ""
-            for i, (upd, k, t, cs) in enumerate(log):
-                if abs(k - t) > 1e-4 * max(abs(t), 1e-9) or cs != ref[i][3]:
-                    flag += " [call %d: kernel %.6f torch %.6f checksums %s vs rank0 %s]" % (i, k, t, cs, ref[i][3])
-            print("rep", rep, "rank", r, "teacher_diff per iteration", tds, "calls", [(round(k, 6), round(t, 6)) for _, k, t, _ in log], flag)
+        for r, tds, rows in got:
+            flag = [(i, row) for i, row in enumerate(rows) if row[4] or abs(row[1] - row[3]) > 1e-5 * max(row[3], 1e-9)]
+            print("rep", rep, "rank", r, "teacher_diff per iteration", tds, "calls (kernel out, sum sqrt kernel sq, sum sqrt torch sq)",
+                  [(round(a, 6), round(b, 6), round(c, 6)) for _, a, b, c, _ in rows], "MISMATCH " + str(flag) if flag else "")
